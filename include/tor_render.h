@@ -1,0 +1,249 @@
+/*
+ * tor_render.h -- C ABI of libtor_mi355x.so: the MI355X (gfx950) implementation of the
+ * trace-of-radiance integrator hot path
+ *     render() -> radiance() -> HittableList.hit -> Material.scatter
+ * (reference: trace_of_radiance/render.nim:21-68).  Plain pointers and sizes only; every
+ * struct is a bit-for-bit mirror of the value type Nim's C backend emits for the reference
+ * type named next to it (x86-64), so a Nim caller passes `unsafeAddr` of its own objects
+ * (see INTEGRATION.md for the {.importc.} shim).
+ *
+ * All arithmetic on the path is IEEE float64 (vec3s.nim:12-14).
+ */
+#ifndef TOR_RENDER_H
+#define TOR_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOR_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------ */
+/* POD mirrors of the reference's value types                                            */
+/* ------------------------------------------------------------------------------------ */
+
+/* Vec3 / Point3 / Color / Attenuation / UnitVector -- primitives/vec3s.nim:12-14 (24 B) */
+typedef struct TorVec3 { double x, y, z; } TorVec3;
+
+/* MaterialKind -- physics/core.nim:25-27 (enum order of registerSubType) */
+enum { TOR_LAMBERTIAN = 0, TOR_METAL = 1, TOR_DIELECTRIC = 2 };
+
+/* Material -- physics/core.nim:16-28 (object variant: kind:uint8 @0, union @8; 40 B) */
+typedef struct TorMaterial {
+  uint8_t kind;
+  uint8_t _pad[7];
+  union {
+    struct { TorVec3 albedo; } lambertian;              /* core.nim:16-17 */
+    struct { TorVec3 albedo; double fuzz; } metal;      /* core.nim:18-20 */
+    struct { double refraction_index; } dielectric;     /* core.nim:21-22 */
+  } u;
+} TorMaterial;
+
+/* Sphere -- physics/hittables/spheres.nim:15-18 (72 B) */
+typedef struct TorSphere {
+  TorVec3 center;
+  double radius;
+  TorMaterial material;
+} TorSphere;
+
+/* MovingSphere -- physics/hittables/moving_spheres.nim:15-20 (112 B) */
+typedef struct TorMovingSphere {
+  TorVec3 center0, center1;
+  double time0, time1;
+  double radius;
+  TorMaterial material;
+} TorMovingSphere;
+
+/* HittableVariantKind -- physics/hittables/hittables_variants.nim:53-54 */
+enum { TOR_SPHERE = 0, TOR_MOVING_SPHERE = 1 };
+
+/* HittableVariant -- hittables_variants.nim:50-57 (kind:uint8 @0, union @8; 120 B) */
+typedef struct TorHittableVariant {
+  uint8_t kind;
+  uint8_t _pad[7];
+  union {
+    TorSphere sphere;
+    TorMovingSphere moving_sphere;
+  } u;
+} TorHittableVariant;
+
+/* HittableList -- physics/hittables/hittables_lists.nim:20-24 (borrowed view; 16 B) */
+typedef struct TorHittableList {
+  int64_t len;
+  const TorHittableVariant* objects;
+} TorHittableList;
+
+/* Camera -- physics/cameras.nim:15-22 (24 float64 in declaration order; 192 B) */
+typedef struct TorCamera {
+  TorVec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+  double lens_radius, shutter_open, shutter_close;
+} TorCamera;
+
+/* Canvas -- primitives/canvas.nim:20-28 (24 B).  pixels: nrows*ncols Colors, row-major,
+ * row 0 = BOTTOM scanline (io/ppm.nim:20); caller-allocated, fully overwritten. */
+typedef struct TorCanvas {
+  TorVec3* pixels;
+  int32_t nrows, ncols;
+  int32_t samples_per_pixel;
+  float gamma_correction;
+} TorCanvas;
+
+/* ------------------------------------------------------------------------------------ */
+/* Options                                                                               */
+/* ------------------------------------------------------------------------------------ */
+
+/* How the per-pixel RNG streams are laid out. */
+enum {
+  /* render.nim:59-67: rng.seed(row,col) once per pixel, the spp samples share one stream.
+   * One GPU lane per PIXEL.  This is the reference's behaviour. */
+  TOR_SEED_PIXEL = 0,
+  /* Counter-based extension (BASELINE.json north_star): the stream is re-seeded per
+   * (row,col,sample): sm=pair(row,col); h=splitMix64(sm); seed(h xor sample).
+   * One GPU lane per PIXEL-SAMPLE; per-pixel sums use exact (2^-36-quantised) float64
+   * addition so the result does not depend on scheduling or device count. */
+  TOR_SEED_SAMPLE = 1
+};
+
+/* Rounding of the ray/sphere quadratic. */
+enum {
+  TOR_ARITH_STRICT = 0, /* reference operation order, no FMA (README.md:82)               */
+  TOR_ARITH_FUSED = 1   /* same formulas with explicit fma(); throughput variant          */
+};
+
+typedef struct TorOptions {
+  uint32_t struct_size; /* = sizeof(TorOptions) */
+  int32_t seeding;      /* TOR_SEED_*  (default TOR_SEED_PIXEL)  */
+  int32_t arith;        /* TOR_ARITH_* (default TOR_ARITH_STRICT) */
+  int32_t device;       /* HIP device ordinal; -1 = current device */
+  /* Row sharding (render.nim:55 `parallelFor row` across GPUs): image rows are cut into
+   * tiles of row_tile rows; tile t is rendered by shard (t mod shard_count).  The shard's
+   * rows are written compactly, in increasing row order.  shard_count <= 1: whole image. */
+  int32_t shard_index, shard_count, row_tile;
+  int32_t reserved;
+} TorOptions;
+
+/* Status codes (the reference's render() returns void and has no error path; this ABI
+ * returns 0 on success and never writes a partial canvas on failure). */
+enum {
+  TOR_OK = 0,
+  TOR_ERR_INVALID_ARGUMENT = -1,
+  TOR_ERR_NO_DEVICE = -2,  /* no HIP device / kernels unavailable: there is NO CPU fallback */
+  TOR_ERR_HIP = -3,
+  TOR_ERR_OUT_OF_MEMORY = -4
+};
+
+/* ------------------------------------------------------------------------------------ */
+/* The drop-in entry point                                                               */
+/* ------------------------------------------------------------------------------------ */
+
+/* Replaces `proc render*(canvas: var Canvas, cam: Camera, world: HittableList,
+ * max_depth: int)` -- render.nim:49.  Blocking: canvas.pixels is complete on return (the
+ * reference's canvas is complete only after exit(Weave)/syncRoot(Weave),
+ * trace_of_radiance.nim:61-63).  Reference semantics: TOR_SEED_PIXEL, TOR_ARITH_STRICT. */
+TOR_API int tor_render(TorCanvas* canvas, const TorCamera* cam, TorHittableList world,
+                       int64_t max_depth);
+
+/* Same with explicit options (NULL = defaults).  With shard_count > 1 only this shard's
+ * rows of canvas->pixels are written (in place, at their image positions). */
+TOR_API int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList world,
+                           int64_t max_depth, const TorOptions* opt);
+
+/* Thread-local description of the last failure (never NULL). */
+TOR_API const char* tor_last_error(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Resident-context API (frame loops: trace_of_radiance_animation.nim:173-196; benchmarks; */
+/* multi-GPU hosts that own device buffers)                                              */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct TorContext TorContext;
+
+TOR_API int tor_context_create(int32_t device, TorContext** out);
+TOR_API int tor_context_destroy(TorContext* ctx);
+
+/* Flattens the AoS HittableVariant list (hittables_lists.nim:41-46) into the device SoA
+ * scene.  The host pointer is not retained. */
+TOR_API int tor_scene_upload(TorContext* ctx, TorHittableList world);
+
+/* Number of rows / list of rows shard (index,count,row_tile) owns. rows_out may be NULL. */
+TOR_API int32_t tor_shard_rows(int32_t nrows, int32_t row_tile, int32_t shard_index,
+                               int32_t shard_count, int32_t* rows_out);
+
+/* Renders this shard's rows into d_pixels, a DEVICE buffer of tor_shard_rows()*ncols*3
+ * float64 (rows in increasing order, gamma-corrected exactly like Canvas.draw,
+ * canvas.nim:47-54).  Asynchronous on hip_stream (a hipStream_t; NULL = default stream);
+ * the buffer is complete when the stream reaches the end of the enqueued work. */
+TOR_API int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols,
+                              int32_t samples_per_pixel, float gamma_correction,
+                              int64_t max_depth, const TorOptions* opt, double* d_pixels,
+                              void* hip_stream);
+
+/* Device-side output stage (io/ppm.nim:15-16 quantiser int(256*clamp(c,0,0.999))):
+ * d_pixels (n_rows*ncols*3 float64) -> d_rgb8 (n_rows*ncols*3 bytes), same row order. */
+TOR_API int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, int64_t n_values,
+                                     uint8_t* d_rgb8, void* hip_stream);
+
+/* Timing of the last tor_render_device call on this context, measured with HIP events
+ * recorded on the launch stream around the integrator kernel only (ms); blocks until the
+ * kernel has finished.  samples_out (nullable) = pixel-samples that launch traced. */
+TOR_API int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out);
+/* Mean duration (ms) of the integrator kernel over the last `last_n` tor_render_device calls
+ * (at most 64 are remembered), from the same per-launch HIP events. */
+TOR_API int tor_kernel_ms_mean(TorContext* ctx, int32_t last_n, float* mean_ms_out, int32_t* n_used_out);
+
+/* Workload counters of the last tor_render_device call (only when the context was told to
+ * collect them, see tor_context_set_stats): closest-hit queries, candidate resolves. */
+typedef struct TorStats {
+  uint64_t hit_queries;       /* world.hit() calls (hittables_lists.nim:48-55)          */
+  uint64_t object_tests;      /* hit_queries * n_objects                                 */
+  uint64_t candidates;        /* objects that survived the discriminant filter           */
+  uint64_t wave_iterations;   /* bounce-loop trips summed over waves                     */
+  uint64_t lane_slots;        /* 64 * wave_iterations                                    */
+  uint64_t samples;           /* pixel-samples traced                                    */
+} TorStats;
+TOR_API int tor_context_set_stats(TorContext* ctx, int32_t enable);
+TOR_API int tor_last_stats(TorContext* ctx, TorStats* out);
+
+/* ------------------------------------------------------------------------------------ */
+/* Host-side mirrors of the reference constructors on either side of the path            */
+/* ------------------------------------------------------------------------------------ */
+
+/* camera(...) -- physics/cameras.nim:24-45 */
+TOR_API int tor_camera_init(TorCamera* out, const TorVec3* look_from, const TorVec3* look_at,
+                            const TorVec3* view_up, double vertical_fov_degrees,
+                            double aspect_ratio, double aperture, double focus_distance,
+                            double shutter_open, double shutter_close);
+
+/* random_scene(rng) with rng.seed(seed) -- scenes.nim:13-50, trace_of_radiance.nim:34-36.
+ * Returns the number of objects written, or a negative status if cap is too small. */
+TOR_API int64_t tor_random_scene(uint64_t seed, TorHittableVariant* out, int64_t cap);
+
+/* exportToPPM's quantiser on a host canvas -- io/ppm.nim:14-27.  out: nrows*ncols*3 bytes,
+ * first row = top scanline. */
+TOR_API int tor_canvas_to_rgb8(const TorCanvas* canvas, uint8_t* out);
+
+/* ------------------------------------------------------------------------------------ */
+/* Self-test probes (used by the parity tests; no effect on rendering)                   */
+/* ------------------------------------------------------------------------------------ */
+
+/* Runs the kernel's own math on the DEVICE: op 0: sin,cos(a)  1: x^5  2: pow(x,y)
+ * 3: sqrt(x)  4: x/y  5: uniform01 of seed(row=x,col=y) first n draws... see tests. */
+TOR_API int tor_selftest_math_device(int32_t op, const double* x, const double* y, double* out0,
+                                     double* out1, int64_t n, int32_t device);
+/* Same routines compiled for the HOST from the same source (no GPU needed). */
+TOR_API int tor_selftest_math_host(int32_t op, const double* x, const double* y, double* out0,
+                                   double* out1, int64_t n);
+/* RNG probes (host build of the kernel's RNG): state after seed, then n draws. */
+TOR_API int tor_selftest_rng_host(int32_t mode, uint64_t a, uint64_t b, uint64_t c,
+                                  uint64_t state_out[4], uint64_t* draws_out, int64_t n);
+
+TOR_API const char* tor_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TOR_RENDER_H */

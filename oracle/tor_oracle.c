@@ -88,6 +88,7 @@ typedef struct {
   int32_t row_begin, row_end; /* render rows [row_begin,row_end) ; other rows untouched */
   int32_t threads;  /* 0 = OpenMP default */
   int32_t collect_stats;
+  int32_t row_step; /* render every row_step-th row starting at row_begin (0/1 = all) */
 } OracleOptions;
 
 typedef struct {
@@ -480,16 +481,19 @@ static Ray camera_ray(const Cam* c, double s, double t, Rng* g, OracleStats* st)
 typedef struct { V3 p, normal; const Obj* obj; double t; int front_face; } HitRecord; /* core.nim:30-36 */
 
 /* moving_spheres.nim:39-44 */
-static inline V3 obj_center(const Obj* o, double time) {
+static inline V3 obj_center(const Obj* o, double time, int arith) {
   V3 c0 = v3(o->c0x, o->c0y, o->c0z);
   if (o->kind == OBJ_SPHERE) return c0;
   V3 c1 = v3(o->c1x, o->c1y, o->c1z);
-  return vadd(c0, vscale(vsub(c1, c0), (time - o->t0) / (o->t1 - o->t0)));
+  V3 dc = vsub(c1, c0);
+  double f = (time - o->t0) / (o->t1 - o->t0);
+  if (arith == 0) return vadd(c0, vscale(dc, f));
+  return v3(fma(dc.x, f, c0.x), fma(dc.y, f, c0.y), fma(dc.z, f, c0.z)); /* FUSED variant */
 }
 
 /* spheres.nim:28-49 and moving_spheres.nim:46-67 (identical but for the centre) */
 static int obj_hit(const Obj* o, const Ray* r, double t_min, double t_max, int arith, HitRecord* rec) {
-  V3 center = obj_center(o, r->time);
+  V3 center = obj_center(o, r->time, arith);
   V3 oc = vsub(r->origin, center);
   double a, half_b, c, disc;
   if (arith == 0) {
@@ -635,6 +639,7 @@ EXPORT int oracle_render(double* pixels, int32_t nrows, int32_t ncols, int32_t s
   o.row_end = nrows;
   if (opt) o = *opt;
   if (o.row_end <= 0 || o.row_end > nrows) o.row_end = nrows;
+  if (o.row_step < 1) o.row_step = 1;
   Cam cam; memcpy(&cam, cam24, sizeof cam);
   const Obj* objs = (const Obj*)objs16;
   if (stats_out) memset(stats_out, 0, sizeof *stats_out);
@@ -646,7 +651,7 @@ EXPORT int oracle_render(double* pixels, int32_t nrows, int32_t ncols, int32_t s
     OracleStats local; memset(&local, 0, sizeof local);
     OracleStats* st = (o.collect_stats && stats_out) ? &local : NULL;
 #pragma omp for schedule(dynamic, 1)
-    for (int32_t row = o.row_begin; row < o.row_end; ++row) {
+    for (int32_t row = o.row_begin; row < o.row_end; row += o.row_step) {
       for (int32_t col = 0; col < ncols; ++col) {
         Rng g;
         if (o.seeding == 0) rng_seed2(&g, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);

@@ -1,0 +1,209 @@
+"""GPU parity: the HIP integrator (through the C ABI) against the CPU oracle on the same
+inputs.  The oracle's PORTABLE math mode is the bit-level twin of the kernel's math (the
+oracle's LIBM mode is what the golden PNG pins; tests/test_oracle_* tie the two together).
+
+Stated tolerance (BASELINE.json north_star): per-channel |delta| <= 1e-5 on the float64 canvas.
+The kernel is built to do better -- bit-exact -- and the tests assert that too."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _render(tor, scene, cam, h, w, spp, depth=50, **opt):
+    cv = tor.new_canvas(h, w, spp, 2.2)
+    tor.render(cv, cam, scene.list(), depth, tor.make_options(**opt) if opt else None)
+    return cv
+
+
+def _assert_parity(got, want, exact=True):
+    assert np.all(np.isfinite(got))
+    err = float(np.max(np.abs(got - want)))
+    assert err <= TOL, f"max per-channel error {err} > {TOL}"
+    if exact:
+        assert np.array_equal(got, want), f"not bit-exact (max err {err}, {(got != want).sum()} values differ)"
+
+
+def test_device_math_is_bit_identical_to_oracle(tor, oracle):
+    L = oracle.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.random(400000) * (2.0 * 3.141592653589793),
+                        np.array([0.0, 1e-300, np.pi / 2, np.pi, np.nextafter(2 * np.pi, 0)])])
+    s, c = tor.selftest_math(0, a)
+    s2 = np.empty_like(a); c2 = np.empty_like(a)
+    L.oracle_port_sincos(dp(a), dp(s2), dp(c2), a.size)
+    assert np.array_equal(s, s2) and np.array_equal(c, c2)
+    x = rng.random(400000) * 2.0
+    p, _ = tor.selftest_math(1, x)
+    p2 = np.empty_like(x); L.oracle_port_pow5(dp(x), dp(p2), x.size)
+    assert np.array_equal(p, p2)
+    g = 1.0 / float(np.float32(2.2))
+    xx = np.concatenate([rng.random(200000), rng.random(200000) * 1e-7, np.array([0.0, 1.0, 2.0 ** -48])])
+    p, _ = tor.selftest_math(2, xx, np.full_like(xx, g))
+    p2 = np.empty_like(xx); L.oracle_port_pow(dp(xx), g, dp(p2), xx.size)
+    assert np.array_equal(p, p2)
+    # IEEE correctly rounded sqrt and division on the device (the path relies on both)
+    y = np.concatenate([rng.random(300000) * 1e3, 10.0 ** rng.uniform(-300, 300, 100000)])
+    r, _ = tor.selftest_math(3, y)
+    assert np.array_equal(r, np.sqrt(y))
+    num = rng.standard_normal(400000) * 10.0 ** rng.uniform(-100, 100, 400000)
+    den = rng.standard_normal(400000) * 10.0 ** rng.uniform(-100, 100, 400000)
+    r, _ = tor.selftest_math(4, num, den)
+    assert np.array_equal(r, num / den)
+    q, _ = tor.selftest_math(5, x)
+    assert np.array_equal(q, np.array([L.oracle_quantize36(float(v)) for v in x[:2000]]).tolist() + q[2000:].tolist())
+    u, _ = tor.selftest_math(6, x, x[::-1].copy())
+    uh, _ = tor.selftest_math(6, x, x[::-1].copy(), where="host")
+    assert np.array_equal(u, uh)
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_pixel_seeding_matches_oracle(tor, oracle, ref_scene, ref_camera, golden_dir, arith):
+    """TOR_SEED_PIXEL = the reference's stream layout (render.nim:59-67)."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = _render(tor, scene, cam, 36, 64, 16, seeding=tor.SEED_PIXEL, arith=arith)
+    want = np.load(os.path.join(golden_dir, "small_canvases.npz"))[f"c_0_1_{arith}_0"]
+    _assert_parity(cv.pixels, want)
+    live = oracle.render(36, 64, 16, ref_camera, objs, seeding=0, math=1, arith=arith).pixels
+    _assert_parity(cv.pixels, live)
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_sample_seeding_matches_oracle(tor, oracle, ref_scene, ref_camera, golden_dir, arith):
+    """TOR_SEED_SAMPLE: one lane per pixel-sample, counter-based streams, exact accumulation."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = _render(tor, scene, cam, 36, 64, 16, seeding=tor.SEED_SAMPLE, arith=arith)
+    z = np.load(os.path.join(golden_dir, "small_canvases.npz"))
+    _assert_parity(cv.pixels, z[f"c_1_1_{arith}_1"])                 # quantised accumulation: exact
+    _assert_parity(cv.pixels, z[f"c_1_1_{arith}_0"], exact=False)    # sequential float64 sum: 1e-5
+    assert float(np.max(np.abs(cv.pixels - z[f"c_1_1_{arith}_0"]))) < 1e-8
+    _assert_parity(cv.pixels, z[f"c_1_0_{arith}_0"], exact=False)    # libm oracle: 1e-5
+
+
+def test_c1_reference_image(tor, oracle, ref_scene, ref_camera, golden_dir):
+    """BASELINE config C1 (384x216, 100 spp, depth 50) == trace_of_radiance.nim main().
+    GPU canvas == oracle canvas bit-for-bit, and its PPM quantisation against the reference's
+    own PNG (the kernel's sin/cos are correctly rounded, glibc's are 1 ulp off in ~0.14 % of
+    calls, so a handful of 8-bit channels may differ)."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = _render(tor, scene, cam, 216, 384, 100)  # tor_render(): reference semantics
+    want = oracle.render(216, 384, 100, ref_camera, objs, seeding=0, math=1, arith=0).pixels
+    _assert_parity(cv.pixels, want)
+    rgb = tor.export_rgb8(cv)
+    g = np.array(Image.open(os.path.join(golden_dir, "book2_motion_blur.png")).convert("RGB"))
+    differ = int((rgb != g).sum())
+    assert differ <= 25, f"{differ} of {g.size} 8-bit channels differ from the reference PNG"
+    assert int(np.abs(rgb.astype(int) - g.astype(int)).max()) <= 8
+
+
+def test_row_sharding_is_exact(tor):
+    """Any row partition gives the same pixels: shards written in place."""
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    for seeding in (tor.SEED_PIXEL, tor.SEED_SAMPLE):
+        full = _render(tor, scene, cam, 45, 80, 8, seeding=seeding).pixels
+        for count, tile in ((2, 1), (3, 4), (8, 2), (4, 16)):
+            cv = tor.new_canvas(45, 80, 8, 2.2)
+            cv.pixels[:] = -1.0
+            for k in range(count):
+                tor.render(cv, cam, scene.list(), 50,
+                           tor.make_options(seeding=seeding, shard_index=k, shard_count=count, row_tile=tile))
+            assert np.array_equal(cv.pixels, full), (seeding, count, tile)
+
+
+def _custom_scene(tor, oracle, recs):
+    recs = np.asarray(recs, dtype=np.float64)
+    return tor.Scene.from_records(recs), recs
+
+
+def test_edge_cases_match_oracle(tor, oracle, ref_camera):
+    cam = tor.camera()
+    # kind c0 c1 t0 t1 radius mat albedo fuzz ri
+    recs = [
+        [0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0],
+        [1, 0, 1, 0, 0, 1.5, 0, 0.0, 1.0, 1.0, 0, .8, .3, .3, 0, 0],       # group (0,1)
+        [1, -4, 1, 0, -4, 1, 1, 0.25, 0.75, 1.0, 1, .7, .6, .5, 0.3, 0],   # group (.25,.75), moves in z
+        [1, 4, 1, 0, 5, 1, 0, 0.25, 0.75, 1.0, 2, 0, 0, 0, 0, 1.5],        # same group, glass, moves in x
+        [1, 2, .5, 2, 2, .5, 2, 0.5, 0.5, 0.5, 0, .1, .9, .1, 0, 0],       # time0 == time1: never hit
+        [0, 1, .4, 3, 1, .4, 3, 0, 1, 0.4, 1, .9, .9, .9, 0.0, 0],
+        [0, 1, .4, 3, 1, .4, 3, 0, 1, 0.4, 0, .2, .2, .9, 0.0, 0],         # exact duplicate: tie -> lowest index
+        [0, -1, .3, 2, -1, .3, 2, 0, 1, -0.3, 2, 0, 0, 0, 0, 1.5],         # negative radius (hollow glass)
+    ]
+    scene, recs = _custom_scene(tor, oracle, recs)
+    for (h, w, spp, depth) in ((24, 40, 8, 50), (2, 2, 4, 50), (7, 13, 3, 1), (9, 5, 2, 2), (16, 16, 1, 50)):
+        for seeding in (0, 1):
+            cv = _render(tor, scene, cam, h, w, spp, depth, seeding=seeding)
+            want = oracle.render(h, w, spp, ref_camera, recs, max_depth=depth, seeding=seeding, math=1,
+                                 arith=0, accum=seeding).pixels
+            _assert_parity(cv.pixels, want)
+    # empty world: sky only (HittableList of length 0)
+    empty = tor.Scene()
+    cv = _render(tor, empty, cam, 8, 8, 4, seeding=0)
+    want = oracle.render(8, 8, 4, ref_camera, np.zeros((0, 16)), seeding=0, math=1).pixels
+    _assert_parity(cv.pixels, want)
+    # max_depth = 0: the bounce loop never runs -> black canvas (render.nim:25,47)
+    cv = _render(tor, scene, cam, 8, 8, 4, 0)
+    assert np.array_equal(cv.pixels, np.zeros((8, 8, 3)))
+    # many objects: queue overflow path (every sphere encloses the camera -> all are candidates)
+    big = [[0, 13, 2, 3, 13, 2, 3, 0, 1, 5.0 + 0.01 * i, 2, 0, 0, 0, 0, 1.5] for i in range(100)]
+    scene2, recs2 = _custom_scene(tor, oracle, big)
+    cv = _render(tor, scene2, cam, 6, 6, 2, 8, seeding=1)
+    want = oracle.render(6, 6, 2, ref_camera, recs2, max_depth=8, seeding=1, math=1, accum=1).pixels
+    _assert_parity(cv.pixels, want)
+
+
+def test_invalid_arguments_fail_loudly(tor):
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    for (h, w, spp) in ((1, 8, 1), (8, 1, 1), (8, 8, 0)):
+        cv = tor.new_canvas(h, w, spp, 2.2)
+        cv.pixels[:] = 7.0
+        with pytest.raises(tor.TorError):
+            tor.render(cv, cam, scene.list(), 50)
+        assert np.all(cv.pixels == 7.0)  # never a partial canvas
+    with pytest.raises(tor.TorError):
+        tor.render(tor.new_canvas(4, 4, 1), cam, scene.list(), 50, tor.make_options(shard_index=3, shard_count=2))
+
+
+def test_full_size_properties(tor):
+    """BASELINE config C2 geometry (1920x1080), size-independent properties: determinism,
+    shard invariance of the device path, finite values in range, quantiser idempotence."""
+    import torch
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    ctx = tor.Context()
+    ctx.upload(scene.list())
+    h, w, spp = 1080, 1920, 8
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for rep in range(2):
+        buf = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        ctx.render_device(cam, h, w, spp, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE), buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        outs.append(buf)
+    assert torch.equal(outs[0], outs[1])                      # atomics order does not matter
+    assert bool(torch.isfinite(outs[0]).all()) and float(outs[0].min()) >= 0.0 and float(outs[0].max()) <= 1.0 + 1e-12
+    parts = torch.full((h, w, 3), -1.0, dtype=torch.float64, device="cuda")
+    for k in range(4):
+        rows = torch.from_numpy(tor.shard_rows(h, 8, k, 4)).long().cuda()
+        shard = torch.empty((len(rows), w, 3), dtype=torch.float64, device="cuda")
+        ctx.render_device(cam, h, w, spp, 2.2, 50,
+                          tor.make_options(seeding=tor.SEED_SAMPLE, shard_index=k, shard_count=4, row_tile=8),
+                          shard.data_ptr(), stream)
+        torch.cuda.synchronize()
+        parts[rows] = shard
+    assert torch.equal(parts, outs[0])
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    ctx.quantize_rgb8_device(outs[0].data_ptr(), outs[0].numel(), rgb.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ref = (256 * outs[0].clamp(0.0, 0.999)).to(torch.int32).to(torch.uint8)
+    assert torch.equal(rgb, ref)
+    ms, n = ctx.last_kernel_ms()
+    assert n == (h // 4 + 0) * 0 + len(tor.shard_rows(h, 8, 3, 4)) * w * spp and ms > 0
+    ctx.close()

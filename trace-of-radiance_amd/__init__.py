@@ -1,0 +1,424 @@
+"""trace-of-radiance on MI355X: host-side mirror of the reference's render() interface.
+
+The product is ``lib/libtor_mi355x.so`` (hand-written HIP kernels for gfx950 behind the C ABI
+declared in ``include/tor_render.h``).  This module is the thin host layer above that ABI; it
+mirrors the names of the reference's own interface for the path
+
+    camera(...)                     physics/cameras.nim:24-45
+    random_scene(seed)              scenes.nim:13-50 (+ trace_of_radiance.nim:34-36)
+    new_canvas / Canvas             primitives/canvas.nim:20-41
+    render(canvas, cam, world, max_depth)   render.nim:49
+    export_rgb8 (exportToPPM's quantiser)   io/ppm.nim:14-27
+
+so the parity tests read like the reference's ``main()`` (trace_of_radiance.nim:26-71).
+There is NO CPU fallback: every rendering call raises ``TorError`` when the HIP extension or a
+GPU is missing.  (The package directory name contains a hyphen; import it with
+``importlib.import_module("trace-of-radiance_amd")``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtor_mi355x.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+SEED_PIXEL, SEED_SAMPLE = 0, 1
+ARITH_STRICT, ARITH_FUSED = 0, 1
+LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
+SPHERE, MOVING_SPHERE = 0, 1
+
+
+class TorError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"tor_mi355x error {code}: {msg}")
+        self.code = code
+
+
+# --------------------------------------------------------------------------------------
+# ABI structs (include/tor_render.h)
+# --------------------------------------------------------------------------------------
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class _Lambertian(C.Structure):
+    _fields_ = [("albedo", Vec3)]
+
+
+class _Metal(C.Structure):
+    _fields_ = [("albedo", Vec3), ("fuzz", C.c_double)]
+
+
+class _Dielectric(C.Structure):
+    _fields_ = [("refraction_index", C.c_double)]
+
+
+class _MaterialU(C.Union):
+    _fields_ = [("lambertian", _Lambertian), ("metal", _Metal), ("dielectric", _Dielectric)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("_pad", C.c_uint8 * 7), ("u", _MaterialU)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", Vec3), ("radius", C.c_double), ("material", Material)]
+
+
+class MovingSphere(C.Structure):
+    _fields_ = [("center0", Vec3), ("center1", Vec3), ("time0", C.c_double), ("time1", C.c_double),
+                ("radius", C.c_double), ("material", Material)]
+
+
+class _HittableU(C.Union):
+    _fields_ = [("sphere", Sphere), ("moving_sphere", MovingSphere)]
+
+
+class HittableVariant(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("_pad", C.c_uint8 * 7), ("u", _HittableU)]
+
+
+class HittableList(C.Structure):
+    _fields_ = [("len", C.c_int64), ("objects", C.POINTER(HittableVariant))]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", Vec3), ("lower_left_corner", Vec3), ("horizontal", Vec3), ("vertical", Vec3),
+                ("u", Vec3), ("v", Vec3), ("w", Vec3), ("lens_radius", C.c_double),
+                ("shutter_open", C.c_double), ("shutter_close", C.c_double)]
+
+    def as_array(self) -> np.ndarray:
+        return np.frombuffer(bytes(self), dtype=np.float64).copy()
+
+
+class CanvasStruct(C.Structure):
+    _fields_ = [("pixels", C.POINTER(Vec3)), ("nrows", C.c_int32), ("ncols", C.c_int32),
+                ("samples_per_pixel", C.c_int32), ("gamma_correction", C.c_float)]
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("seeding", C.c_int32), ("arith", C.c_int32),
+                ("device", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
+                ("row_tile", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("hit_queries", C.c_uint64), ("object_tests", C.c_uint64), ("candidates", C.c_uint64),
+                ("wave_iterations", C.c_uint64), ("lane_slots", C.c_uint64), ("samples", C.c_uint64)]
+
+
+assert C.sizeof(Vec3) == 24 and C.sizeof(Material) == 40 and C.sizeof(Sphere) == 72
+assert C.sizeof(MovingSphere) == 112 and C.sizeof(HittableVariant) == 120
+assert C.sizeof(HittableList) == 16 and C.sizeof(Camera) == 192 and C.sizeof(CanvasStruct) == 24
+
+EXPORTED_SYMBOLS = [
+    "tor_render", "tor_render_opt", "tor_last_error", "tor_context_create", "tor_context_destroy",
+    "tor_scene_upload", "tor_shard_rows", "tor_render_device", "tor_quantize_rgb8_device",
+    "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_camera_init",
+    "tor_random_scene", "tor_canvas_to_rgb8", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_selftest_rng_host", "tor_version",
+]
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libtor_mi355x.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-C", src_dir, "-B", "all"], check=True, capture_output=True)
+    else:
+        subprocess.run(["make", "-C", src_dir, "all"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def lib():
+    """Load the HIP extension; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TorError(-2, f"HIP extension missing: {LIB_PATH} (run __graft_entry__.build()); "
+                           "there is no CPU fallback")
+    # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Two HIP/HSA
+    # runtimes in one process cannot both open the GPU, so when torch is installed it must be
+    # loaded FIRST: the dynamic loader then binds this library's NEEDED libamdhip64.so.7 to the
+    # already-loaded copy and device pointers / streams are shared with torch.
+    if os.environ.get("TOR_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    L.tor_last_error.restype = C.c_char_p
+    L.tor_version.restype = C.c_char_p
+    L.tor_render.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), HittableList, C.c_int64]
+    L.tor_render_opt.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), HittableList, C.c_int64,
+                                 C.POINTER(Options)]
+    L.tor_context_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    L.tor_context_destroy.argtypes = [C.c_void_p]
+    L.tor_scene_upload.argtypes = [C.c_void_p, HittableList]
+    L.tor_shard_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    L.tor_shard_rows.restype = C.c_int32
+    L.tor_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_float, C.c_int64, C.POINTER(Options), C.c_void_p, C.c_void_p]
+    L.tor_quantize_rgb8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.tor_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+    L.tor_kernel_ms_mean.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.tor_context_set_stats.argtypes = [C.c_void_p, C.c_int32]
+    L.tor_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.tor_camera_init.argtypes = [C.POINTER(Camera), C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Vec3)] + \
+                                 [C.c_double] * 6
+    L.tor_random_scene.argtypes = [C.c_uint64, C.POINTER(HittableVariant), C.c_int64]
+    L.tor_random_scene.restype = C.c_int64
+    L.tor_canvas_to_rgb8.argtypes = [C.POINTER(CanvasStruct), C.POINTER(C.c_uint8)]
+    L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
+    L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
+    L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int64]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise TorError(rc, lib().tor_last_error().decode("utf-8", "replace"))
+
+
+# --------------------------------------------------------------------------------------
+# Reference-interface mirrors
+# --------------------------------------------------------------------------------------
+def vec3(x, y, z) -> Vec3:
+    return Vec3(float(x), float(y), float(z))
+
+
+def camera(look_from=(13, 2, 3), look_at=(0, 0, 0), view_up=(0, 1, 0), vertical_field_of_view=20.0,
+           aspect_ratio=16.0 / 9.0, aperture=0.1, focus_distance=10.0, shutter_open=0.0,
+           shutter_close=1.0) -> Camera:
+    """camera() -- physics/cameras.nim:24-45; defaults = trace_of_radiance.nim:38-51."""
+    cam = Camera()
+    a, b, c = vec3(*look_from), vec3(*look_at), vec3(*view_up)
+    _check(lib().tor_camera_init(C.byref(cam), C.byref(a), C.byref(b), C.byref(c),
+                                 vertical_field_of_view, aspect_ratio, aperture, focus_distance,
+                                 shutter_open, shutter_close))
+    return cam
+
+
+class Scene:
+    """Scene / HittableList -- physics/hittables/hittables_lists.nim:15-46 (owner + borrowed view)."""
+
+    def __init__(self, objects=None, n: int = 0):
+        self.objects = objects if objects is not None else (HittableVariant * 1)()
+        self.n = n
+
+    def list(self) -> HittableList:
+        return HittableList(self.n, C.cast(self.objects, C.POINTER(HittableVariant)))
+
+    def __len__(self):
+        return self.n
+
+    @staticmethod
+    def from_records(recs: np.ndarray) -> "Scene":
+        """Build from the oracle's flat (n,16) float64 records (tests only)."""
+        n = int(recs.shape[0])
+        arr = (HittableVariant * max(n, 1))()
+        for i in range(n):
+            r = recs[i]
+            h = arr[i]
+            mat = Material()
+            mat.kind = int(r[10])
+            if mat.kind == LAMBERTIAN:
+                mat.u.lambertian.albedo = vec3(r[11], r[12], r[13])
+            elif mat.kind == METAL:
+                mat.u.metal.albedo = vec3(r[11], r[12], r[13])
+                mat.u.metal.fuzz = float(r[14])
+            else:
+                mat.u.dielectric.refraction_index = float(r[15])
+            if int(r[0]) == SPHERE:
+                h.kind = SPHERE
+                h.u.sphere.center = vec3(r[1], r[2], r[3])
+                h.u.sphere.radius = float(r[9])
+                h.u.sphere.material = mat
+            else:
+                h.kind = MOVING_SPHERE
+                h.u.moving_sphere.center0 = vec3(r[1], r[2], r[3])
+                h.u.moving_sphere.center1 = vec3(r[4], r[5], r[6])
+                h.u.moving_sphere.time0 = float(r[7])
+                h.u.moving_sphere.time1 = float(r[8])
+                h.u.moving_sphere.radius = float(r[9])
+                h.u.moving_sphere.material = mat
+        return Scene(arr, n)
+
+    def to_records(self) -> np.ndarray:
+        """Flat (n,16) float64 records in the oracle's field order (tests only)."""
+        out = np.zeros((self.n, 16), dtype=np.float64)
+        for i in range(self.n):
+            h = self.objects[i]
+            if h.kind == SPHERE:
+                s = h.u.sphere
+                c0 = c1 = s.center
+                t0, t1, rad, m = 0.0, 1.0, s.radius, s.material
+            else:
+                s = h.u.moving_sphere
+                c0, c1, t0, t1, rad, m = s.center0, s.center1, s.time0, s.time1, s.radius, s.material
+            out[i, 0] = h.kind
+            out[i, 1:4] = (c0.x, c0.y, c0.z)
+            out[i, 4:7] = (c1.x, c1.y, c1.z)
+            out[i, 7:10] = (t0, t1, rad)
+            out[i, 10] = m.kind
+            if m.kind == LAMBERTIAN:
+                a = m.u.lambertian.albedo
+                out[i, 11:14] = (a.x, a.y, a.z)
+            elif m.kind == METAL:
+                a = m.u.metal.albedo
+                out[i, 11:14] = (a.x, a.y, a.z)
+                out[i, 14] = m.u.metal.fuzz
+            else:
+                out[i, 15] = m.u.dielectric.refraction_index
+        return out
+
+
+def random_scene(seed: int = 0xFACADE) -> Scene:
+    """random_scene(rng) with rng.seed(seed) -- scenes.nim:13-50."""
+    cap = 2048
+    arr = (HittableVariant * cap)()
+    n = lib().tor_random_scene(seed, arr, cap)
+    if n < 0:
+        raise TorError(int(n), "tor_random_scene failed")
+    return Scene(arr, int(n))
+
+
+class Canvas:
+    """Canvas -- primitives/canvas.nim:20-41: row-major float64 RGB, row 0 = bottom scanline."""
+
+    def __init__(self, height: int, width: int, samples_per_pixel: int, gamma_correction: float = 2.2):
+        self.pixels = np.zeros((height, width, 3), dtype=np.float64)
+        self.nrows, self.ncols = int(height), int(width)
+        self.samples_per_pixel = int(samples_per_pixel)
+        self.gamma_correction = float(gamma_correction)
+
+    def struct(self) -> CanvasStruct:
+        return CanvasStruct(self.pixels.ctypes.data_as(C.POINTER(Vec3)), self.nrows, self.ncols,
+                            self.samples_per_pixel, self.gamma_correction)
+
+
+def new_canvas(height, width, samples_per_pixel, gamma_correction=2.2) -> Canvas:
+    return Canvas(height, width, samples_per_pixel, gamma_correction)
+
+
+def make_options(seeding=SEED_PIXEL, arith=ARITH_STRICT, device=-1, shard_index=0, shard_count=1,
+                 row_tile=1) -> Options:
+    return Options(C.sizeof(Options), seeding, arith, device, shard_index, shard_count, row_tile, 0)
+
+
+def render(canvas: Canvas, cam: Camera, world: HittableList, max_depth: int, options: Options | None = None):
+    """render(canvas, cam, world, max_depth) -- render.nim:49.  Blocking."""
+    cs = canvas.struct()
+    if options is None:
+        _check(lib().tor_render(C.byref(cs), C.byref(cam), world, int(max_depth)))
+    else:
+        _check(lib().tor_render_opt(C.byref(cs), C.byref(cam), world, int(max_depth), C.byref(options)))
+
+
+def export_rgb8(canvas: Canvas) -> np.ndarray:
+    """exportToPPM's quantiser (io/ppm.nim:14-27): uint8 (nrows, ncols, 3), first row = top."""
+    out = np.zeros((canvas.nrows, canvas.ncols, 3), dtype=np.uint8)
+    cs = canvas.struct()
+    _check(lib().tor_canvas_to_rgb8(C.byref(cs), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def export_ppm(canvas: Canvas, f) -> None:
+    """exportToPPM(canvas, f) -- io/ppm.nim:14-27 (ASCII P3)."""
+    rgb = export_rgb8(canvas)
+    f.write(f"P3\n{canvas.ncols} {canvas.nrows}\n255\n")
+    for r, g, b in rgb.reshape(-1, 3):
+        f.write(f"{r} {g} {b}\n")
+
+
+def shard_rows(nrows: int, row_tile: int, shard_index: int, shard_count: int) -> np.ndarray:
+    buf = (C.c_int32 * max(nrows, 1))()
+    n = lib().tor_shard_rows(nrows, row_tile, shard_index, shard_count, buf)
+    return np.array(buf[:n], dtype=np.int32)
+
+
+class Context:
+    """Resident device context (tor_context_* / tor_scene_upload / tor_render_device)."""
+
+    def __init__(self, device: int = -1):
+        self._h = C.c_void_p()
+        _check(lib().tor_context_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tor_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, world: HittableList):
+        _check(lib().tor_scene_upload(self._h, world))
+
+    def set_stats(self, enable: bool):
+        _check(lib().tor_context_set_stats(self._h, int(enable)))
+
+    def render_device(self, cam: Camera, nrows: int, ncols: int, spp: int, gamma: float, max_depth: int,
+                      options: Options, d_pixels_ptr: int, stream_ptr: int = 0):
+        """Asynchronous on the given hipStream_t; d_pixels_ptr is a device pointer."""
+        _check(lib().tor_render_device(self._h, C.byref(cam), nrows, ncols, spp, gamma, int(max_depth),
+                                       C.byref(options), C.c_void_p(d_pixels_ptr), C.c_void_p(stream_ptr)))
+
+    def quantize_rgb8_device(self, d_pixels_ptr: int, n_values: int, d_rgb8_ptr: int, stream_ptr: int = 0):
+        _check(lib().tor_quantize_rgb8_device(self._h, C.c_void_p(d_pixels_ptr), n_values,
+                                              C.c_void_p(d_rgb8_ptr), C.c_void_p(stream_ptr)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        n = C.c_int64(0)
+        _check(lib().tor_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def kernel_ms_mean(self, last_n: int):
+        ms = C.c_float(0)
+        n = C.c_int32(0)
+        _check(lib().tor_kernel_ms_mean(self._h, last_n, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def last_stats(self) -> Stats:
+        st = Stats()
+        _check(lib().tor_last_stats(self._h, C.byref(st)))
+        return st
+
+
+def selftest_math(op: int, x: np.ndarray, y: np.ndarray | None = None, where: str = "device", device: int = -1):
+    """Run the kernel's math routines on arrays (op: 0 sincos, 1 x^5, 2 pow, 3 sqrt, 4 div, 5 quantize)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    yy = np.ascontiguousarray(y, dtype=np.float64) if y is not None else None
+    o0 = np.zeros_like(x)
+    o1 = np.zeros_like(x)
+    dp = C.POINTER(C.c_double)
+    yp = yy.ctypes.data_as(dp) if yy is not None else None
+    if where == "device":
+        _check(lib().tor_selftest_math_device(op, x.ctypes.data_as(dp), yp, o0.ctypes.data_as(dp),
+                                              o1.ctypes.data_as(dp), x.size, device))
+    else:
+        _check(lib().tor_selftest_math_host(op, x.ctypes.data_as(dp), yp, o0.ctypes.data_as(dp),
+                                            o1.ctypes.data_as(dp), x.size))
+    return o0, o1
+
+
+def selftest_rng(mode: int, a: int, b: int = 0, c: int = 0, n: int = 4):
+    state = (C.c_uint64 * 4)()
+    draws = (C.c_uint64 * max(n, 1))()
+    _check(lib().tor_selftest_rng_host(mode, a, b, c, state, draws, n))
+    return [int(v) for v in state], [int(v) for v in draws[:n]]

@@ -1,0 +1,563 @@
+// tor_api.cpp -- the C ABI of libtor_mi355x.so (include/tor_render.h): context, scene
+// flattening (AoS HittableVariant -> device SoA), launch orchestration, error reporting.
+// There is NO CPU fallback: without a HIP device every rendering entry point fails with
+// TOR_ERR_NO_DEVICE.
+#include "../../include/tor_render.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tor_kernels.hpp"
+
+// ---- layout guards: the structs must match what Nim's C backend emits --------
+static_assert(sizeof(TorVec3) == 24, "Vec3 is 3 x float64 (vec3s.nim:12-14)");
+static_assert(sizeof(TorMaterial) == 40 && offsetof(TorMaterial, u) == 8, "Material (core.nim:16-28)");
+static_assert(sizeof(TorSphere) == 72, "Sphere (spheres.nim:15-18)");
+static_assert(sizeof(TorMovingSphere) == 112, "MovingSphere (moving_spheres.nim:15-20)");
+static_assert(sizeof(TorHittableVariant) == 120 && offsetof(TorHittableVariant, u) == 8,
+              "HittableVariant (hittables_variants.nim:50-57)");
+static_assert(sizeof(TorHittableList) == 16, "HittableList (hittables_lists.nim:20-24)");
+static_assert(sizeof(TorCamera) == 192, "Camera (cameras.nim:15-22)");
+static_assert(sizeof(TorCanvas) == 24, "Canvas (canvas.nim:20-28)");
+static_assert(sizeof(tor::Camera) == sizeof(TorCamera), "device camera mirrors TorCamera");
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int fail_hip(hipError_t e, const char* what) {
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+    return fail(TOR_ERR_NO_DEVICE, m + " (libtor_mi355x has no CPU fallback)");
+  if (e == hipErrorOutOfMemory) return fail(TOR_ERR_OUT_OF_MEMORY, m);
+  return fail(TOR_ERR_HIP, m);
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e__ = (expr);                           \
+    if (e__ != hipSuccess) return fail_hip(e__, #expr); \
+  } while (0)
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&ptr, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct TorContext {
+  int device = 0;
+  int num_cus = 0;
+  // scene
+  DeviceBuffer stat, mov, segs, cold;
+  int n_segs = 0;
+  int64_t n_objects = 0;
+  bool scene_ready = false;
+  // work
+  DeviceBuffer counters;  // [0] work counter, [1..4] stats
+  DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
+  bool collect_stats = false;
+  static constexpr int kEventRing = 64;
+  hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
+  int64_t launches = 0;  // timed integrator launches so far
+  bool timing_valid = false;
+  int64_t last_samples = 0;
+  int blocks_per_cu[2][2] = {{0, 0}, {0, 0}};
+};
+
+namespace {
+
+bool valid_options(const TorOptions* opt, TorOptions& o) {
+  o = TorOptions{};
+  o.struct_size = sizeof(TorOptions);
+  o.seeding = TOR_SEED_PIXEL;
+  o.arith = TOR_ARITH_STRICT;
+  o.device = -1;
+  o.shard_index = 0;
+  o.shard_count = 1;
+  o.row_tile = 1;
+  if (opt) {
+    if (opt->struct_size != sizeof(TorOptions)) return false;
+    o = *opt;
+  }
+  if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return false;
+  if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return false;
+  if (o.shard_count < 1) o.shard_count = 1;
+  if (o.row_tile < 1) o.row_tile = 1;
+  if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
+  return true;
+}
+
+inline double i64_as_double(int64_t v) {
+  double d;
+  std::memcpy(&d, &v, 8);
+  return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tor_last_error(void) { return g_last_error.c_str(); }
+
+const char* tor_version(void) { return "tor_mi355x 0.1 (gfx950)"; }
+
+int tor_context_create(int32_t device, TorContext** out) {
+  if (!out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_context_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(TOR_ERR_NO_DEVICE,
+                std::string("no HIP device available (") + hipGetErrorString(e) +
+                    "); libtor_mi355x has no CPU fallback");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= count) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_context_create: device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  TorContext* ctx = new (std::nothrow) TorContext();
+  if (!ctx) return fail(TOR_ERR_OUT_OF_MEMORY, "tor_context_create: host allocation failed");
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail_hip(e, "hipGetDeviceProperties");
+  }
+  ctx->num_cus = prop.multiProcessorCount;
+  e = ctx->counters.ensure(8 * sizeof(unsigned long long));
+  for (int i = 0; i < TorContext::kEventRing && e == hipSuccess; ++i) {
+    e = hipEventCreate(&ctx->ev_start[i]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop[i]);
+  }
+  if (e != hipSuccess) {
+    tor_context_destroy(ctx);
+    return fail_hip(e, "tor_context_create");
+  }
+  *out = ctx;
+  return TOR_OK;
+}
+
+int tor_context_destroy(TorContext* ctx) {
+  if (!ctx) return TOR_OK;
+  (void)hipSetDevice(ctx->device);
+  ctx->stat.release();
+  ctx->mov.release();
+  ctx->segs.release();
+  ctx->cold.release();
+  ctx->counters.release();
+  ctx->scratch.release();
+  for (int i = 0; i < TorContext::kEventRing; ++i) {
+    if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+    if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+  }
+  delete ctx;
+  return TOR_OK;
+}
+
+int tor_context_set_stats(TorContext* ctx, int32_t enable) {
+  if (!ctx) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_context_set_stats: ctx is NULL");
+  ctx->collect_stats = enable != 0;
+  return TOR_OK;
+}
+
+// AoS -> SoA.  Objects are partitioned into one static segment and one segment per distinct
+// (time0, time1) pair; closest-hit is order independent (hittables_lists.nim:48-55; ties are
+// broken by the original index carried in the cold record), so the reordering is exact.
+int tor_scene_upload(TorContext* ctx, TorHittableList world) {
+  if (!ctx) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: ctx is NULL");
+  if (world.len < 0 || (world.len > 0 && !world.objects))
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: bad HittableList");
+  if (world.len > (int64_t)1 << 24) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: too many objects");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int64_t n = world.len;
+  std::vector<int64_t> statics;
+  std::vector<std::pair<std::pair<uint64_t, uint64_t>, std::vector<int64_t>>> groups;
+  for (int64_t i = 0; i < n; ++i) {
+    const TorHittableVariant& h = world.objects[i];
+    if (h.kind == TOR_SPHERE) {
+      statics.push_back(i);
+    } else if (h.kind == TOR_MOVING_SPHERE) {
+      uint64_t k0, k1;
+      std::memcpy(&k0, &h.u.moving_sphere.time0, 8);
+      std::memcpy(&k1, &h.u.moving_sphere.time1, 8);
+      bool found = false;
+      for (auto& g : groups)
+        if (g.first.first == k0 && g.first.second == k1) {
+          g.second.push_back(i);
+          found = true;
+          break;
+        }
+      if (!found) groups.push_back({{k0, k1}, {i}});
+    } else {
+      return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown HittableVariant kind");
+    }
+  }
+  auto padded = [](size_t c) { return (c + tor::kPad - 1) / tor::kPad * tor::kPad; };
+  const size_t n_stat_p = padded(statics.size());
+  size_t n_mov_p = 0;
+  for (auto& g : groups) n_mov_p += padded(g.second.size());
+  const size_t n_sorted = n_stat_p + n_mov_p;
+  std::vector<double> stat(4 * n_stat_p + 4, 0.0), mov(8 * n_mov_p + 8, 0.0), cold(16 * n_sorted + 16, 0.0);
+  std::vector<double> segs;
+  // padding record: centre 0, radius^2 = -1  => discriminant <= -|d|^2 < 0, never a candidate
+  for (size_t k = 0; k < n_stat_p; ++k) stat[4 * k + 3] = -1.0;
+  for (size_t k = 0; k < n_mov_p; ++k) mov[8 * k + 3] = -1.0;
+
+  auto fill_material = [&](double* c, const TorMaterial& m, int moving) -> bool {
+    int64_t flags = (moving ? 1 : 0) | ((int64_t)m.kind << 8);
+    c[13] = i64_as_double(flags);
+    switch (m.kind) {
+      case TOR_LAMBERTIAN:
+        c[9] = m.u.lambertian.albedo.x; c[10] = m.u.lambertian.albedo.y; c[11] = m.u.lambertian.albedo.z;
+        return true;
+      case TOR_METAL:
+        c[9] = m.u.metal.albedo.x; c[10] = m.u.metal.albedo.y; c[11] = m.u.metal.albedo.z;
+        c[12] = m.u.metal.fuzz;
+        return true;
+      case TOR_DIELECTRIC:
+        c[12] = m.u.dielectric.refraction_index;
+        return true;
+      default:
+        return false;
+    }
+  };
+
+  size_t sorted = 0;
+  if (!statics.empty()) {
+    segs.insert(segs.end(), {0.0, 0.0, (double)n_stat_p, 0.0, 0.0, 0.0, 0.0, 0.0});
+    for (size_t k = 0; k < statics.size(); ++k) {
+      const TorSphere& s = world.objects[statics[k]].u.sphere;
+      stat[4 * k + 0] = s.center.x; stat[4 * k + 1] = s.center.y; stat[4 * k + 2] = s.center.z;
+      stat[4 * k + 3] = s.radius * s.radius;  // spheres.nim:32 `self.radius*self.radius`
+      double* c = &cold[16 * (sorted + k)];
+      c[0] = s.center.x; c[1] = s.center.y; c[2] = s.center.z;
+      c[6] = 1.0 / s.radius;  // vec3s.nim:93-94: `/ radius` is `* (1.0 / radius)`
+      c[14] = i64_as_double(statics[k]);
+      c[15] = s.radius * s.radius;
+      if (!fill_material(c, s.material, 0)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown Material kind");
+    }
+    sorted += n_stat_p;
+  }
+  size_t mov_rec = 0;
+  for (auto& g : groups) {
+    const size_t cnt_p = padded(g.second.size());
+    const TorMovingSphere& first = world.objects[g.second[0]].u.moving_sphere;
+    const double t0 = first.time0, dt = first.time1 - first.time0;  // moving_spheres.nim:42
+    segs.insert(segs.end(), {1.0, (double)mov_rec, (double)cnt_p, (double)sorted, t0, dt, 0.0, 0.0});
+    for (size_t k = 0; k < g.second.size(); ++k) {
+      const TorMovingSphere& s = world.objects[g.second[k]].u.moving_sphere;
+      double* m = &mov[8 * (mov_rec + k)];
+      const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y,
+                   dcz = s.center1.z - s.center0.z;  // moving_spheres.nim:43
+      m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+      m[3] = s.radius * s.radius;
+      m[4] = dcx; m[5] = dcy; m[6] = dcz;
+      double* c = &cold[16 * (sorted + k)];
+      c[0] = s.center0.x; c[1] = s.center0.y; c[2] = s.center0.z;
+      c[3] = dcx; c[4] = dcy; c[5] = dcz;
+      c[6] = 1.0 / s.radius;
+      c[7] = t0; c[8] = dt;
+      c[14] = i64_as_double(g.second[k]);
+      c[15] = s.radius * s.radius;
+      if (!fill_material(c, s.material, 1)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown Material kind");
+    }
+    mov_rec += cnt_p;
+    sorted += cnt_p;
+  }
+  if (segs.empty()) segs.assign(8, 0.0);  // empty world: one empty static segment
+  ctx->n_segs = (int)(n == 0 ? 0 : segs.size() / 8);
+
+  HIP_TRY(ctx->stat.ensure(stat.size() * 8));
+  HIP_TRY(ctx->mov.ensure(mov.size() * 8));
+  HIP_TRY(ctx->segs.ensure(segs.size() * 8));
+  HIP_TRY(ctx->cold.ensure(cold.size() * 8));
+  HIP_TRY(hipMemcpy(ctx->stat.ptr, stat.data(), stat.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->mov.ptr, mov.data(), mov.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->segs.ptr, segs.data(), segs.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->cold.ptr, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
+  ctx->n_objects = n;
+  ctx->scene_ready = true;
+  return TOR_OK;
+}
+
+int32_t tor_shard_rows(int32_t nrows, int32_t row_tile, int32_t shard_index, int32_t shard_count,
+                       int32_t* rows_out) {
+  if (nrows <= 0) return 0;
+  if (shard_count < 1) shard_count = 1;
+  if (row_tile < 1) row_tile = 1;
+  if (shard_index < 0 || shard_index >= shard_count) return 0;
+  int32_t n = 0;
+  for (int32_t r = 0; r < nrows; ++r)
+    if ((r / row_tile) % shard_count == shard_index) {
+      if (rows_out) rows_out[n] = r;
+      ++n;
+    }
+  return n;
+}
+
+int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols,
+                      int32_t spp, float gamma_correction, int64_t max_depth, const TorOptions* opt,
+                      double* d_pixels, void* hip_stream) {
+  if (!ctx || !cam || !d_pixels) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: NULL argument");
+  if (!ctx->scene_ready) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: no scene uploaded");
+  // The reference divides by (ncols-1) and (nrows-1) (render.nim:64-65) and by spp
+  // (canvas.nim:49); degenerate sizes are rejected instead of producing inf/NaN canvases.
+  if (nrows < 2 || ncols < 2 || spp < 1)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: need nrows >= 2, ncols >= 2, samples_per_pixel >= 1");
+  if (max_depth > 0x7fffffff) max_depth = 0x7fffffff;
+  TorOptions o;
+  if (!valid_options(opt, o)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: bad TorOptions");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  const int32_t local_rows = tor_shard_rows(nrows, o.row_tile, o.shard_index, o.shard_count, nullptr);
+  const long long npix = (long long)local_rows * ncols;
+  const long long n_values = npix * 3;
+  ctx->timing_valid = false;
+  ctx->last_samples = 0;
+  if (npix == 0) return TOR_OK;
+
+  HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long), stream));
+  if (max_depth <= 0 || ctx->n_objects < 0) {
+    // render.nim:25: the bounce loop does not run -> every sample is black -> pow(0, g) = 0
+    HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
+    return TOR_OK;
+  }
+  if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
+
+  int& bpc = ctx->blocks_per_cu[o.seeding][o.arith];
+  if (bpc == 0) bpc = tor::integrate_blocks_per_cu(o.seeding, o.arith);
+  const long long resident_waves = (long long)ctx->num_cus * bpc * (tor::kThreads / 64);
+
+  tor::KParams p{};
+  p.stat = (const double*)ctx->stat.ptr;
+  p.mov = (const double*)ctx->mov.ptr;
+  p.segs = (const double*)ctx->segs.ptr;
+  p.cold = (const double*)ctx->cold.ptr;
+  p.n_segs = ctx->n_segs;
+  p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
+  p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
+  p.work_counter = (unsigned long long*)ctx->counters.ptr;
+  p.stats = ctx->collect_stats ? (unsigned long long*)ctx->counters.ptr + 1 : nullptr;
+  p.out = d_pixels;
+  std::memcpy(&p.cam, cam, sizeof(TorCamera));
+
+  long long waves;
+  if (o.seeding == TOR_SEED_PIXEL) {
+    p.total_work = (unsigned long long)npix;
+    p.chunk = 64;
+    waves = (npix + 63) / 64;
+  } else {
+    p.total_work = (unsigned long long)npix * (unsigned long long)spp;
+    long long c = (long long)(p.total_work / (unsigned long long)(resident_waves * 16));
+    if (c < 64) c = 64;
+    if (c > 16384) c = 16384;
+    p.chunk = (unsigned)(c / 64 * 64);
+    waves = (long long)((p.total_work + 63) / 64);
+  }
+  if (waves > resident_waves) waves = resident_waves;
+  int blocks = (int)((waves + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
+  if (blocks < 1) blocks = 1;
+
+  const int slot = (int)(ctx->launches % TorContext::kEventRing);
+  HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+  HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, blocks, stream));
+  HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+  ctx->launches += 1;
+  ctx->timing_valid = true;
+  ctx->last_samples = (int64_t)npix * spp;
+  // canvas.nim:47-54
+  const double scale = 1.0 / (double)spp;
+  const double gamma = 1.0 / (double)gamma_correction;
+  HIP_TRY(tor::launch_finalize(d_pixels, n_values, scale, gamma, stream));
+  return TOR_OK;
+}
+
+int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, int64_t n_values, uint8_t* d_rgb8,
+                             void* hip_stream) {
+  if (!ctx || !d_pixels || !d_rgb8 || n_values < 0)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_quantize_rgb8_device: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(tor::launch_quantize(d_pixels, n_values, d_rgb8, (hipStream_t)hip_stream));
+  return TOR_OK;
+}
+
+int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out) {
+  if (!ctx || !ms_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_kernel_ms: NULL argument");
+  if (!ctx->timing_valid) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_kernel_ms: no timed launch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int slot = (int)((ctx->launches - 1) % TorContext::kEventRing);
+  HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
+  HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev_start[slot], ctx->ev_stop[slot]));
+  if (samples_out) *samples_out = ctx->last_samples;
+  return TOR_OK;
+}
+
+int tor_kernel_ms_mean(TorContext* ctx, int32_t last_n, float* mean_ms_out, int32_t* n_used_out) {
+  if (!ctx || !mean_ms_out || last_n < 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_kernel_ms_mean: bad argument");
+  if (!ctx->timing_valid || ctx->launches < 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_kernel_ms_mean: no timed launch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int64_t n = last_n;
+  if (n > ctx->launches) n = ctx->launches;
+  if (n > TorContext::kEventRing) n = TorContext::kEventRing;
+  double sum = 0.0;
+  for (int64_t k = 0; k < n; ++k) {
+    const int slot = (int)((ctx->launches - 1 - k) % TorContext::kEventRing);
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+    sum += ms;
+  }
+  *mean_ms_out = (float)(sum / (double)n);
+  if (n_used_out) *n_used_out = (int32_t)n;
+  return TOR_OK;
+}
+
+int tor_last_stats(TorContext* ctx, TorStats* out) {
+  if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: NULL argument");
+  if (!ctx->collect_stats) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: stats not enabled");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long h[8];
+  HIP_TRY(hipMemcpy(h, ctx->counters.ptr, sizeof h, hipMemcpyDeviceToHost));
+  out->hit_queries = h[1];
+  out->object_tests = h[1] * (uint64_t)ctx->n_objects;
+  out->candidates = h[2];
+  out->wave_iterations = h[3];
+  out->lane_slots = h[3] * 64;
+  out->samples = h[4];
+  return TOR_OK;
+}
+
+// ---- the drop-in: host canvas in, host canvas out ---------------------------------------
+
+static std::mutex g_ctx_mutex;
+static std::map<int, TorContext*> g_default_ctx;  // one cached context per device
+
+int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, int64_t max_depth,
+                   const TorOptions* opt) {
+  if (!canvas || !cam || !canvas->pixels) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: NULL argument");
+  TorOptions o;
+  if (!valid_options(opt, o)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: bad TorOptions");
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  int device = o.device;
+  if (device < 0) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+      return fail(TOR_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                         "); libtor_mi355x has no CPU fallback");
+    HIP_TRY(hipGetDevice(&device));
+  }
+  TorContext*& ctx = g_default_ctx[device];
+  if (!ctx) {
+    int rc = tor_context_create(device, &ctx);
+    if (rc != TOR_OK) { ctx = nullptr; return rc; }
+  }
+  int rc = tor_scene_upload(ctx, world);
+  if (rc != TOR_OK) return rc;
+  const int32_t nrows = canvas->nrows, ncols = canvas->ncols;
+  std::vector<int32_t> rows((size_t)(nrows > 0 ? nrows : 0));
+  const int32_t local_rows = tor_shard_rows(nrows, o.row_tile, o.shard_index, o.shard_count, rows.data());
+  const size_t row_bytes = (size_t)ncols * 24;
+  HIP_TRY(ctx->scratch.ensure((size_t)(local_rows > 0 ? local_rows : 1) * row_bytes));
+  rc = tor_render_device(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction,
+                         max_depth, &o, (double*)ctx->scratch.ptr, nullptr);
+  if (rc != TOR_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (o.shard_count <= 1) {
+    HIP_TRY(hipMemcpy(canvas->pixels, ctx->scratch.ptr, (size_t)nrows * row_bytes, hipMemcpyDeviceToHost));
+  } else {
+    for (int32_t lr = 0; lr < local_rows; ++lr)
+      HIP_TRY(hipMemcpy((char*)canvas->pixels + (size_t)rows[lr] * row_bytes,
+                        (char*)ctx->scratch.ptr + (size_t)lr * row_bytes, row_bytes, hipMemcpyDeviceToHost));
+  }
+  return TOR_OK;
+}
+
+int tor_render(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, int64_t max_depth) {
+  return tor_render_opt(canvas, cam, world, max_depth, nullptr);
+}
+
+// ---- self tests -----------------------------------------------------------------------------
+
+int tor_selftest_math_host(int32_t op, const double* x, const double* y, double* out0, double* out1,
+                           int64_t n) {
+  if (!x || !out0 || n < 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_math_host: bad argument");
+  for (int64_t i = 0; i < n; ++i) {
+    double a = 0, b = 0;
+    tor::selftest_math_one(op, x[i], y ? y[i] : 0.0, a, b);
+    out0[i] = a;
+    if (out1) out1[i] = b;
+  }
+  return TOR_OK;
+}
+
+int tor_selftest_math_device(int32_t op, const double* x, const double* y, double* out0, double* out1,
+                             int64_t n, int32_t device) {
+  if (!x || !out0 || n < 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_math_device: bad argument");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail(TOR_ERR_NO_DEVICE, "no HIP device available");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  const size_t bytes = (size_t)n * 8;
+  double *dx = nullptr, *dy = nullptr, *d0 = nullptr, *d1 = nullptr;
+  HIP_TRY(hipMalloc((void**)&dx, bytes + 8));
+  HIP_TRY(hipMalloc((void**)&dy, bytes + 8));
+  HIP_TRY(hipMalloc((void**)&d0, bytes + 8));
+  HIP_TRY(hipMalloc((void**)&d1, bytes + 8));
+  HIP_TRY(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+  if (y) HIP_TRY(hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemset(dy, 0, bytes));
+  HIP_TRY(hipMemset(d0, 0, bytes));
+  HIP_TRY(hipMemset(d1, 0, bytes));
+  HIP_TRY(tor::launch_selftest(op, dx, dy, d0, d1, n, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost));
+  if (out1) HIP_TRY(hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(d0); (void)hipFree(d1);
+  return TOR_OK;
+}
+
+int tor_selftest_rng_host(int32_t mode, uint64_t a, uint64_t b, uint64_t c, uint64_t state_out[4],
+                          uint64_t* draws_out, int64_t n) {
+  tor::Rng g{0, 0, 0, 0};
+  if (mode == 1) tor::seed1(g, a);
+  else if (mode == 2) tor::seed2(g, a, b);
+  else if (mode == 3) tor::seed3(g, a, b, c);
+  else return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_rng_host: mode must be 1, 2 or 3");
+  if (state_out) { state_out[0] = g.s0; state_out[1] = g.s1; state_out[2] = g.s2; state_out[3] = g.s3; }
+  for (int64_t i = 0; i < n && draws_out; ++i) draws_out[i] = tor::next(g);
+  return TOR_OK;
+}
+
+}  // extern "C"

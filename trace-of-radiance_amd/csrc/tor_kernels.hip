@@ -1,0 +1,487 @@
+// tor_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the trace-of-radiance integrator.
+//
+//   integrate_kernel<SEEDING, ARITH>
+//     render.nim:49-68 (render) + render.nim:21-47 (radiance) + hittables_lists.nim:48-55
+//     (closest hit) + spheres.nim:28-49 / moving_spheres.nim:46-67 + materials.nim:21-96.
+//
+//     Persistent waves with path regeneration: every lane owns one path at a time; a lane
+//     whose path ended (sky, absorbed, depth exhausted) is refilled at the top of the next
+//     bounce iteration with the next work item (wave ballot + prefix count over a wave-uniform
+//     range that is itself pulled in chunks from one global counter).  So the hot loop --
+//     the brute-force ray x all-objects test, >95 % of the float64 work -- always runs with
+//     full waves, whatever the mix of path lengths (1..max_depth).
+//       TOR_SEED_PIXEL : work item = pixel; the lane runs that pixel's spp samples in order on
+//                        the pixel's own stream and sums them in sample order (bit-faithful
+//                        to render.nim:59-67).
+//       TOR_SEED_SAMPLE: work item = pixel-sample; per-sample stream; radiance is rounded to
+//                        2^-36 and accumulated with float64 atomics -- every partial sum is
+//                        exact, so the pixel is independent of scheduling.
+//
+//     Objects are wave-uniform inside the hot loop, so their records come through the scalar
+//     data path (s_load into SGPRs, constant bus operand of the VALU op): no VGPRs, no LDS
+//     bandwidth, no per-lane addresses.  Per test the lanes compute only the discriminant of
+//     the quadratic (17 float64 ops for a static sphere) and a sign-bit filter; the square
+//     root and the two divisions of the reference's `hit` are deferred to a short per-lane
+//     pass over the few objects whose discriminant was positive (queued in LDS).  Closest
+//     hit is order independent (hittables_lists.nim:48-55: strict `<`, ties keep the lowest
+//     index) so the deferred pass reproduces the sequential scan exactly.
+//
+//   finalize_kernel   canvas.nim:47-54 (draw): pow(sum * 1/spp, 1/gamma)
+//   quantize_kernel   io/ppm.nim:15-16
+//
+// float64 throughout, no FMA contraction (-ffp-contract=off); TOR_ARITH_FUSED uses explicit
+// fma() in the discriminant only.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tor_device.hpp"
+#include "tor_kernels.hpp"
+
+namespace tor {
+
+// scalar (constant address space) view of the read-only scene so the compiler emits s_load
+typedef const double __attribute__((address_space(4))) * cdptr;
+typedef const int32_t __attribute__((address_space(4))) * ciptr;
+
+__device__ __forceinline__ cdptr as_const(const double* p) { return (cdptr)(uintptr_t)p; }
+
+__device__ __forceinline__ int hi32(double x) { return __double2hiint(x); }
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __ballot(p); }
+
+__device__ __forceinline__ unsigned lane_prefix(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long bcast_first_u64(unsigned long long v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// One ray/object discriminant, strict or fused.  Returns the sign-bit filter word: negative
+// (bit 31 set) iff disc has a clear sign bit (disc >= +0 or NaN+) and (half_b < 0 or c < 0),
+// a superset of the objects the reference's hit() can accept (both roots are <= 0 when
+// half_b >= 0 and c >= 0).
+template <int ARITH>
+__device__ __forceinline__ int disc_filter(double ox, double oy, double oz, double dx, double dy,
+                                           double dz, double a, double cx, double cy, double cz,
+                                           double r2) {
+  double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+  double hb, cc, disc;
+  if (ARITH == 0) {
+    hb = ocx * dx + ocy * dy + ocz * dz;          // spheres.nim:31
+    cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;  // spheres.nim:32
+    disc = hb * hb - a * cc;                      // spheres.nim:33
+  } else {
+    hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+    cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
+    disc = fma_(hb, hb, -(a * cc));
+  }
+  return (hi32(hb) | hi32(cc)) & ~hi32(disc);
+}
+
+constexpr int kQCap = 32;   // candidate queue entries per lane (LDS, u32)
+constexpr int kUnroll = 8;  // objects per overflow check; hot arrays are padded to this
+
+template <int SEEDING, int ARITH>
+__global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned* smem = reinterpret_cast<unsigned*>(smem_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  unsigned* q = smem + wave * (kQCap * 64) + lane;  // q[k * 64]: k-th candidate of this lane
+
+  const cdptr stat = as_const(p.stat);
+  const cdptr mov = as_const(p.mov);
+  const cdptr segs = as_const(p.segs);
+  const Camera cam = p.cam;
+  const double inv_w = (double)(p.ncols - 1);  // render.nim:64 divides by float64(ncols-1)
+  const double inv_h = (double)(p.nrows - 1);
+
+  // ---- lane state ------------------------------------------------------------------
+  bool active = false;     // owns a live path
+  bool have_item = false;  // SEED_PIXEL: owns a pixel with samples left
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), att = v3(1, 1, 1);
+  double time = 0.0;
+  Rng rng{0, 0, 0, 0};
+  int depth = 0;
+  int row = 0, col = 0, s = 0;
+  long long pix = -1;       // index into p.out (local pixel)
+  V3 acc = v3(0, 0, 0);     // SEED_PIXEL: pixel sum; SEED_SAMPLE: partial sum for acc_pix
+  long long acc_pix = -1;
+
+  // ---- wave-uniform work range ---------------------------------------------------------
+  unsigned long long w_next = 0, w_end = 0;
+  bool exhausted = false;
+  unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
+
+  for (;;) {
+    // ================= (A) refill lanes that have no live path =========================
+    bool need_fetch = !active && !have_item;
+    unsigned long long need_mask = ballot64(need_fetch);
+    if (need_mask != 0) {
+      if (w_next >= w_end && !exhausted) {
+        unsigned long long base = 0;
+        if (lane == (int)__builtin_ctzll(need_mask)) base = atomicAdd(p.work_counter, (unsigned long long)p.chunk);
+        base = bcast_first_u64(__shfl(base, (int)__builtin_ctzll(need_mask)));
+        if (base >= p.total_work) {
+          exhausted = true;
+        } else {
+          w_next = base;
+          w_end = (base + p.chunk < p.total_work) ? base + p.chunk : p.total_work;
+        }
+      }
+      if (w_next < w_end) {
+        unsigned prefix = lane_prefix(need_mask);
+        unsigned long long idx = w_next + prefix;
+        bool got = need_fetch && idx < w_end;
+        unsigned long long avail = w_end - w_next;
+        unsigned long long want = (unsigned long long)__builtin_popcountll(need_mask);
+        w_next += (want < avail) ? want : avail;
+        if (got) {
+          // work index -> (local pixel, sample)
+          unsigned long long pl;
+          if (SEEDING == 0) {
+            pl = idx;
+            s = 0;
+            acc = v3(0, 0, 0);
+          } else {
+            pl = idx / (unsigned)p.spp;
+            s = (int)(idx - pl * (unsigned)p.spp);
+          }
+          unsigned lrow = (unsigned)(pl / (unsigned)p.ncols);
+          col = (int)(pl - (unsigned long long)lrow * (unsigned)p.ncols);
+          // local row -> image row (tiles of row_tile rows dealt round-robin to the shards)
+          unsigned tile = lrow / (unsigned)p.row_tile;
+          unsigned within = lrow - tile * (unsigned)p.row_tile;
+          row = (int)((tile * (unsigned)p.shard_count + (unsigned)p.shard_index) * (unsigned)p.row_tile + within);
+          pix = (long long)pl;
+          have_item = true;
+          if (SEEDING == 0) seed2(rng, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);  // render.nim:59-60
+        }
+      }
+    }
+    if (!active && have_item) {
+      if (SEEDING == 1) {
+        seed3(rng, (uint64_t)row, (uint64_t)col, (uint64_t)s);
+        have_item = false;  // a sample item is consumed by starting it
+      }
+      // render.nim:64-66
+      double u = ((double)col + uniform01(rng)) / inv_w;
+      double v = ((double)row + uniform01(rng)) / inv_h;
+      Ray r = camera_ray(cam, u, v, rng);
+      o = r.origin;
+      d = r.direction;
+      time = r.time;
+      att = v3(1.0, 1.0, 1.0);  // render.nim:22
+      depth = 0;
+      active = true;
+    }
+    unsigned long long active_mask = ballot64(active);
+    if (active_mask == 0) {
+      if (exhausted) break;
+      continue;
+    }
+    st_iters += 1;
+    st_queries += (unsigned long long)__builtin_popcountll(active_mask);
+
+    if (active) {
+      // ================= (B) closest hit over all objects ==============================
+      // hittables_lists.nim:48-55 with t_min = 0.001, t_max = Inf (render.nim:28)
+      const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+      const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
+      const double a = (ARITH == 0) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
+      double best_t = __builtin_inf();
+      int best_idx = -1;
+      int best_orig = 0x7fffffff;
+      double best_f = 0.0;
+
+      int seg = 0;
+      int i = 0;
+      for (;;) {
+        unsigned qn = 0;
+        bool full = false;
+        while (seg < p.n_segs) {
+          const int seg_kind = (int)segs[seg * 8 + 0];
+          const int seg_begin = (int)segs[seg * 8 + 1];   // first hot record / first sorted index
+          const int seg_count = (int)segs[seg * 8 + 2];   // padded to kUnroll
+          const int seg_sorted0 = (int)segs[seg * 8 + 3]; // sorted index of record 0
+          if (seg_kind == 0) {
+            for (; i < seg_count; i += kUnroll) {
+#pragma unroll
+              for (int j = 0; j < kUnroll; ++j) {
+                const int k = seg_begin + i + j;
+                const double cx = stat[4 * k + 0], cy = stat[4 * k + 1], cz = stat[4 * k + 2];
+                const double r2 = stat[4 * k + 3];
+                int t = disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, r2);
+                q[qn * 64] = (unsigned)(seg_sorted0 + i + j);
+                qn += (unsigned)t >> 31;
+              }
+              if (ballot64(qn > (unsigned)(kQCap - kUnroll)) != 0) { full = true; i += kUnroll; break; }
+            }
+          } else {
+            // moving_spheres.nim:39-44: f = (time - time0) / (time1 - time0)
+            const double t0 = segs[seg * 8 + 4], dt = segs[seg * 8 + 5];
+            const double f = (time - t0) / dt;
+            for (; i < seg_count; i += kUnroll) {
+#pragma unroll
+              for (int j = 0; j < kUnroll; ++j) {
+                const int k = seg_begin + i + j;
+                const double c0x = mov[8 * k + 0], c0y = mov[8 * k + 1], c0z = mov[8 * k + 2];
+                const double r2 = mov[8 * k + 3];
+                const double dcx = mov[8 * k + 4], dcy = mov[8 * k + 5], dcz = mov[8 * k + 6];
+                double cx, cy, cz;
+                if (ARITH == 0) {
+                  cx = c0x + dcx * f; cy = c0y + dcy * f; cz = c0z + dcz * f;
+                } else {
+                  cx = fma_(dcx, f, c0x); cy = fma_(dcy, f, c0y); cz = fma_(dcz, f, c0z);
+                }
+                int t = disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, r2);
+                q[qn * 64] = (unsigned)(seg_sorted0 + i + j);
+                qn += (unsigned)t >> 31;
+              }
+              if (ballot64(qn > (unsigned)(kQCap - kUnroll)) != 0) { full = true; i += kUnroll; break; }
+            }
+          }
+          if (full) break;
+          seg += 1;
+          i = 0;
+        }
+
+        // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
+        st_cand += (unsigned long long)qn;  // per-lane; reduced at the end
+        for (unsigned k = 0; ballot64(k < qn) != 0; ++k) {
+          if (k < qn) {
+            const unsigned idx = q[k * 64];
+            const double* c = p.cold + (size_t)idx * 16;
+            const double c0x = c[0], c0y = c[1], c0z = c[2];
+            const double r2 = c[15];
+            const int flags = (int)__double_as_longlong(c[13]);
+            double cx = c0x, cy = c0y, cz = c0z, f = 0.0;
+            if (flags & 1) {
+              f = (time - c[7]) / c[8];
+              if (ARITH == 0) {
+                cx = c0x + c[3] * f; cy = c0y + c[4] * f; cz = c0z + c[5] * f;
+              } else {
+                cx = fma_(c[3], f, c0x); cy = fma_(c[4], f, c0y); cz = fma_(c[5], f, c0z);
+              }
+            }
+            double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+            double hb, cc, disc;
+            if (ARITH == 0) {
+              hb = ocx * dx + ocy * dy + ocz * dz;
+              cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+              disc = hb * hb - a * cc;
+            } else {
+              hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+              cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
+              disc = fma_(hb, hb, -(a * cc));
+            }
+            if (disc > 0.0) {
+              const double root = __builtin_sqrt(disc);
+              double sol = (-hb - root) / a;
+              bool ok = (0.001 < sol) && (sol < __builtin_inf());
+              if (!ok) {
+                sol = (-hb + root) / a;
+                ok = (0.001 < sol) && (sol < __builtin_inf());
+              }
+              if (ok) {
+                const int orig = (int)__double_as_longlong(c[14]);
+                if (sol < best_t || (sol == best_t && orig < best_orig)) {
+                  best_t = sol;
+                  best_idx = (int)idx;
+                  best_orig = orig;
+                  best_f = f;
+                }
+              }
+            }
+          }
+        }
+        if (!full) break;
+      }
+
+      // ================= (C) shade ====================================================
+      bool ended = false;
+      V3 radiance = v3(0.0, 0.0, 0.0);
+      if (best_idx < 0) {
+        radiance = sky(d, att);  // render.nim:41-45
+        ended = true;
+      } else {
+        const double* c = p.cold + (size_t)best_idx * 16;
+        const int flags = (int)__double_as_longlong(c[13]);
+        V3 center = v3(c[0], c[1], c[2]);
+        if (flags & 1) {
+          if (ARITH == 0) center = center + v3(c[3], c[4], c[5]) * best_f;
+          else center = v3(fma_(c[3], best_f, c[0]), fma_(c[4], best_f, c[1]), fma_(c[5], best_f, c[2]));
+        }
+        const V3 hp = o + d * best_t;                       // rays.nim:24-25
+        const V3 outward = (hp - center) * c[6];            // spheres.nim:43 (c[6] = 1.0/radius)
+        const bool front = dot(d, outward) < 0.0;           // core.nim:47-49
+        const V3 n = front ? outward : -outward;
+        const int mat = (flags >> 8) & 0xff;
+        const V3 albedo = v3(c[9], c[10], c[11]);
+        if (mat == kLambertian) {  // materials.nim:24-30
+          d = n + random_unit_vector(rng);
+          o = hp;
+          att = mul_att(att, albedo);  // render.nim:35
+        } else if (mat == kMetal) {  // materials.nim:39-47
+          V3 reflected = reflect(unit_vector(d), n);
+          V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
+          o = hp;
+          d = nd;
+          time = 0.0;  // rays.nim:19 default
+          if (dot(nd, n) > 0.0) {
+            att = mul_att(att, albedo);
+          } else {
+            ended = true;  // render.nim:38: absorbed -> black
+          }
+        } else {  // materials.nim:62-86
+          const double ri = c[12];
+          const double eta = front ? 1.0 / ri : ri;
+          const V3 ud = unit_vector(d);
+          const double dn = dot(-ud, n);
+          const double cos_theta = (dn <= 1.0) ? dn : 1.0;
+          const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+          V3 nd;
+          if (eta * sin_theta > 1.0) {
+            nd = reflect(ud, n);
+          } else {
+            const double reflect_prob = schlick(cos_theta, eta);
+            if (uniform01(rng) < reflect_prob) nd = reflect(ud, n);
+            else nd = refract(ud, n, eta);
+          }
+          o = hp;
+          d = nd;
+          time = 0.0;
+          att = mul_att(att, v3(1.0, 1.0, 1.0));
+        }
+        if (!ended) {
+          depth += 1;
+          if (depth >= p.max_depth) ended = true;  // render.nim:25,47: loop exhausted -> black
+        }
+      }
+
+      if (ended) {
+        active = false;
+        st_samples += 1;
+        if (SEEDING == 0) {
+          acc = acc + radiance;  // render.nim:67
+          s += 1;
+          if (s >= p.spp) {
+            double* out = p.out + (size_t)pix * 3;
+            out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+            have_item = false;
+          }
+        } else {
+          if (acc_pix != pix) {
+            if (acc_pix >= 0) {
+              double* out = p.out + (size_t)acc_pix * 3;
+              unsafeAtomicAdd(out + 0, acc.x);
+              unsafeAtomicAdd(out + 1, acc.y);
+              unsafeAtomicAdd(out + 2, acc.z);
+            }
+            acc = v3(0, 0, 0);
+            acc_pix = pix;
+          }
+          acc = acc + v3(quantize36(radiance.x), quantize36(radiance.y), quantize36(radiance.z));
+        }
+      }
+    }
+  }
+
+  if (SEEDING == 1 && acc_pix >= 0) {
+    double* out = p.out + (size_t)acc_pix * 3;
+    unsafeAtomicAdd(out + 0, acc.x);
+    unsafeAtomicAdd(out + 1, acc.y);
+    unsafeAtomicAdd(out + 2, acc.z);
+  }
+  if (p.stats != nullptr) {
+    // per-lane counters -> wave sums
+    unsigned long long cand = st_cand, smp = st_samples;
+    for (int off = 32; off > 0; off >>= 1) {
+      cand += __shfl_xor(cand, off);
+      smp += __shfl_xor(smp, off);
+    }
+    if (lane == 0) {
+      atomicAdd(p.stats + 0, st_queries);
+      atomicAdd(p.stats + 1, cand);
+      atomicAdd(p.stats + 2, st_iters);
+      atomicAdd(p.stats + 3, smp);
+    }
+  }
+}
+
+// canvas.nim:47-54
+__global__ __launch_bounds__(256) void finalize_kernel(double* pixels, long long n_values, double scale,
+                                                        double gamma) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_values) pixels[i] = pow_pos(scale * pixels[i], gamma);
+}
+
+// io/ppm.nim:15-16 ; safe_math.nim:10-14
+__global__ __launch_bounds__(256) void quantize_kernel(const double* pixels, long long n_values, uint8_t* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_values) {
+    double c = pixels[i];
+    double cl = (c < 0.0) ? 0.0 : ((c > 0.999) ? 0.999 : c);
+    out[i] = (uint8_t)(int)(256 * cl);
+  }
+}
+
+__global__ void selftest_kernel(int op, const double* x, const double* y, double* out0, double* out1,
+                                long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  selftest_math_one(op, x[i], y ? y[i] : 0.0, out0[i], out1 ? out1[i] : out0[i]);
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers (called from tor_api.cpp)
+// ---------------------------------------------------------------------------------------
+hipError_t launch_integrate(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream) {
+  const size_t smem = (size_t)kQCap * 64 * sizeof(unsigned) * (kThreads / 64);
+  dim3 grid((unsigned)blocks), block(kThreads);
+  if (seeding == 0 && arith == 0) hipLaunchKernelGGL((integrate_kernel<0, 0>), grid, block, smem, stream, p);
+  else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1>), grid, block, smem, stream, p);
+  else if (seeding == 1 && arith == 0) hipLaunchKernelGGL((integrate_kernel<1, 0>), grid, block, smem, stream, p);
+  else hipLaunchKernelGGL((integrate_kernel<1, 1>), grid, block, smem, stream, p);
+  return hipGetLastError();
+}
+
+int integrate_blocks_per_cu(int seeding, int arith) {
+  const size_t smem = (size_t)kQCap * 64 * sizeof(unsigned) * (kThreads / 64);
+  int n = 0;
+  hipError_t e;
+  if (seeding == 0 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 0>, kThreads, smem);
+  else if (seeding == 0 && arith == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 1>, kThreads, smem);
+  else if (seeding == 1 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 0>, kThreads, smem);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 1>, kThreads, smem);
+  if (e != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
+hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {
+  if (n_values <= 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n_values + 255) / 256);
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, stream, pixels, n_values, scale, gamma);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream) {
+  if (n_values <= 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n_values + 255) / 256);
+  hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(256), 0, stream, pixels, n_values, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
+                           hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(selftest_kernel, dim3(blocks), dim3(256), 0, stream, op, x, y, out0, out1, n);
+  return hipGetLastError();
+}
+
+}  // namespace tor

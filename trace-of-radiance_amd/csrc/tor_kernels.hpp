@@ -1,0 +1,67 @@
+// tor_kernels.hpp -- launch interface between the C-ABI layer (tor_api.cpp) and the gfx950
+// kernels (tor_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "tor_device.hpp"
+
+namespace tor {
+
+constexpr int kThreads = 256;  // 4 waves per workgroup
+constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of this (= kUnroll)
+
+// Device scene (built by tor_scene_upload from the AoS HittableVariant list):
+//   stat : static spheres, 4 float64 each   {cx, cy, cz, radius^2}
+//   mov  : moving spheres, 8 float64 each   {c0x, c0y, c0z, radius^2, dcx, dcy, dcz, 0}
+//          with dc = center1 - center0, grouped by (time0, time1)
+//   segs : 8 float64 per segment {kind (0 static, 1 moving), first record, padded count,
+//          first sorted index, time0, time1 - time0, 0, 0}
+//   cold : 16 float64 per sorted slot {c0 xyz, dc xyz, 1/radius, time0, time1-time0,
+//          albedo xyz, fuzz|refraction_index, flags(bit0 moving, bits 8..15 material kind),
+//          original index, radius^2}; flags/original index are int64 bit patterns.
+struct KParams {
+  const double* stat;
+  const double* mov;
+  const double* segs;
+  const double* cold;
+  int n_segs;
+  int nrows, ncols, spp, max_depth;
+  int shard_index, shard_count, row_tile;
+  unsigned chunk;
+  unsigned long long total_work;
+  unsigned long long* work_counter;
+  double* out;
+  unsigned long long* stats;  // nullable: {queries, candidates, wave iterations, samples}
+  Camera cam;
+};
+
+hipError_t launch_integrate(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream);
+int integrate_blocks_per_cu(int seeding, int arith);
+hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
+hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
+hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
+                           hipStream_t stream);
+
+// One element of the math self-test (same source compiled for host and device).
+TOR_HD void selftest_math_one(int op, double x, double y, double& out0, double& out1) {
+  switch (op) {
+    case 0: sincos_2pi(x, out0, out1); break;
+    case 1: out0 = pow5(x); break;
+    case 2: out0 = pow_pos(x, y); break;
+    case 3: out0 = __builtin_sqrt(x); break;
+    case 4: out0 = x / y; break;
+    case 5: out0 = quantize36(x); break;
+    case 6: {  // unit_vector((x, y, 0.5)) . (1, 2, 3): exercises reciprocal-multiply normalise
+      V3 u = unit_vector(v3(x, y, 0.5));
+      out0 = dot(u, v3(1.0, 2.0, 3.0));
+      out1 = u.x;
+      break;
+    }
+    default: out0 = x; break;
+  }
+}
+
+}  // namespace tor

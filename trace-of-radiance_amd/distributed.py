@@ -1,0 +1,65 @@
+"""Multi-GPU frame assembly: render.nim:55's `parallelFor row` spread over the GPUs of a node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU
+tests).  Rows are cut into tiles of ``row_tile`` rows and tile t belongs to rank t mod world,
+which evens out the per-row cost (sky rows need ~1 closest-hit query per sample, rows through
+the spheres several).  Each rank renders its rows into a compact shard; ONE all_gather moves
+the shards (49.8 MB for a 1080p float64 frame: 6.2 MB per rank over its own xGMI link), then
+an index copy puts the rows in place.  Pixels do not depend on the partition (per-pixel /
+per-sample RNG streams), so the assembled frame is bit-identical for every world size.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class ShardPlan:
+    def __init__(self, nrows: int, row_tile: int, world: int):
+        self.nrows, self.row_tile, self.world = int(nrows), max(int(row_tile), 1), max(int(world), 1)
+        r = np.arange(self.nrows)
+        owner = (r // self.row_tile) % self.world
+        self.rows = [r[owner == k].astype(np.int64) for k in range(self.world)]  # increasing order
+        self.max_rows = max((len(x) for x in self.rows), default=0)
+
+    def rows_of(self, rank: int) -> np.ndarray:
+        return self.rows[rank]
+
+    def assemble(self, gathered, out=None):
+        """gathered: tensor (world, max_rows, ncols, 3) from all_gather -> (nrows, ncols, 3)."""
+        import torch
+        if out is None:
+            out = torch.empty((self.nrows,) + tuple(gathered.shape[2:]), dtype=gathered.dtype,
+                              device=gathered.device)
+        for k in range(self.world):
+            idx = torch.as_tensor(self.rows[k], device=gathered.device)
+            out.index_copy_(0, idx, gathered[k, : len(self.rows[k])])
+        return out
+
+
+class DistributedFrame:
+    """Buffers + the gather for one frame size; reused across frames."""
+
+    def __init__(self, plan: ShardPlan, ncols: int, rank: int, device, dtype=None):
+        import torch
+        self.plan, self.rank, self.ncols = plan, rank, ncols
+        dtype = dtype or torch.float64
+        self.my_rows = plan.rows_of(rank)
+        # the shard is a view of the (padded) send buffer: no copy before the collective
+        self.send = torch.zeros((plan.max_rows, ncols, 3), dtype=dtype, device=device)
+        self.shard = self.send[: len(self.my_rows)]
+        # flat (world*max_rows, ncols, 3) for the collective (the concatenated form every backend
+        # accepts), viewed per rank for the assembly
+        self._gathered_flat = torch.empty((plan.world * plan.max_rows, ncols, 3), dtype=dtype, device=device)
+        self.gathered = self._gathered_flat.view(plan.world, plan.max_rows, ncols, 3)
+        self.frame = torch.empty((plan.nrows, ncols, 3), dtype=dtype, device=device)
+        self._idx = [torch.as_tensor(plan.rows[k], device=device) for k in range(plan.world)]
+
+    def gather(self):
+        import torch.distributed as dist
+        if self.plan.world > 1:
+            dist.all_gather_into_tensor(self._gathered_flat, self.send)
+            for k in range(self.plan.world):
+                self.frame.index_copy_(0, self._idx[k], self.gathered[k, : len(self.plan.rows[k])])
+        else:
+            self.frame.copy_(self.shard)
+        return self.frame
