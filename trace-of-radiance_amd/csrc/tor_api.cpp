@@ -78,7 +78,7 @@ struct TorContext {
   int device = 0;
   int num_cus = 0;
   // scene
-  DeviceBuffer stat, mov, segs, cold;
+  DeviceBuffer stat, mov, movy, segs, cold;
   int n_segs = 0;
   int64_t n_objects = 0;
   bool scene_ready = false;
@@ -171,6 +171,7 @@ int tor_context_destroy(TorContext* ctx) {
   (void)hipSetDevice(ctx->device);
   ctx->stat.release();
   ctx->mov.release();
+  ctx->movy.release();
   ctx->segs.release();
   ctx->cold.release();
   ctx->counters.release();
@@ -223,14 +224,27 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
   }
   auto padded = [](size_t c) { return (c + tor::kPad - 1) / tor::kPad * tor::kPad; };
   const size_t n_stat_p = padded(statics.size());
-  size_t n_mov_p = 0;
-  for (auto& g : groups) n_mov_p += padded(g.second.size());
-  const size_t n_sorted = n_stat_p + n_mov_p;
-  std::vector<double> stat(4 * n_stat_p + 4, 0.0), mov(8 * n_mov_p + 8, 0.0), cold(16 * n_sorted + 16, 0.0);
+  // a group moves "along y only" when every member has center1.x == center0.x and
+  // center1.z == center0.z: then c0 + f*(c1-c0) leaves x and z untouched, exactly
+  std::vector<char> yonly(groups.size(), 0);
+  size_t n_mov_p = 0, n_movy_p = 0;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    bool y = true;
+    for (int64_t idx : groups[gi].second) {
+      const TorMovingSphere& s = world.objects[idx].u.moving_sphere;
+      if (!(s.center1.x - s.center0.x == 0.0 && s.center1.z - s.center0.z == 0.0)) { y = false; break; }
+    }
+    yonly[gi] = y ? 1 : 0;
+    (y ? n_movy_p : n_mov_p) += padded(groups[gi].second.size());
+  }
+  const size_t n_sorted = n_stat_p + n_mov_p + n_movy_p;
+  std::vector<double> stat(4 * n_stat_p + 8, 0.0), mov(8 * n_mov_p + 8, 0.0), movy(6 * n_movy_p + 8, 0.0),
+      cold(16 * n_sorted + 16, 0.0);
   std::vector<double> segs;
   // padding record: centre 0, radius^2 = -1  => discriminant <= -|d|^2 < 0, never a candidate
   for (size_t k = 0; k < n_stat_p; ++k) stat[4 * k + 3] = -1.0;
   for (size_t k = 0; k < n_mov_p; ++k) mov[8 * k + 3] = -1.0;
+  for (size_t k = 0; k < n_movy_p; ++k) movy[6 * k + 3] = -1.0;
 
   auto fill_material = [&](double* c, const TorMaterial& m, int moving) -> bool {
     int64_t flags = (moving ? 1 : 0) | ((int64_t)m.kind << 8);
@@ -267,20 +281,30 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
     }
     sorted += n_stat_p;
   }
-  size_t mov_rec = 0;
-  for (auto& g : groups) {
+  size_t mov_rec = 0, movy_rec = 0;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    auto& g = groups[gi];
     const size_t cnt_p = padded(g.second.size());
     const TorMovingSphere& first = world.objects[g.second[0]].u.moving_sphere;
     const double t0 = first.time0, dt = first.time1 - first.time0;  // moving_spheres.nim:42
-    segs.insert(segs.end(), {1.0, (double)mov_rec, (double)cnt_p, (double)sorted, t0, dt, 0.0, 0.0});
+    const bool y = yonly[gi] != 0;
+    segs.insert(segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)cnt_p,
+                             (double)(sorted / tor::kPad), t0, dt, 0.0, 0.0});
     for (size_t k = 0; k < g.second.size(); ++k) {
       const TorMovingSphere& s = world.objects[g.second[k]].u.moving_sphere;
-      double* m = &mov[8 * (mov_rec + k)];
       const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y,
                    dcz = s.center1.z - s.center0.z;  // moving_spheres.nim:43
-      m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
-      m[3] = s.radius * s.radius;
-      m[4] = dcx; m[5] = dcy; m[6] = dcz;
+      if (y) {
+        double* m = &movy[6 * (movy_rec + k)];
+        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+        m[3] = s.radius * s.radius;
+        m[4] = dcy;
+      } else {
+        double* m = &mov[8 * (mov_rec + k)];
+        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+        m[3] = s.radius * s.radius;
+        m[4] = dcx; m[5] = dcy; m[6] = dcz;
+      }
       double* c = &cold[16 * (sorted + k)];
       c[0] = s.center0.x; c[1] = s.center0.y; c[2] = s.center0.z;
       c[3] = dcx; c[4] = dcy; c[5] = dcz;
@@ -290,7 +314,7 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
       c[15] = s.radius * s.radius;
       if (!fill_material(c, s.material, 1)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown Material kind");
     }
-    mov_rec += cnt_p;
+    (y ? movy_rec : mov_rec) += cnt_p;
     sorted += cnt_p;
   }
   if (segs.empty()) segs.assign(8, 0.0);  // empty world: one empty static segment
@@ -298,10 +322,12 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
 
   HIP_TRY(ctx->stat.ensure(stat.size() * 8));
   HIP_TRY(ctx->mov.ensure(mov.size() * 8));
+  HIP_TRY(ctx->movy.ensure(movy.size() * 8));
   HIP_TRY(ctx->segs.ensure(segs.size() * 8));
   HIP_TRY(ctx->cold.ensure(cold.size() * 8));
   HIP_TRY(hipMemcpy(ctx->stat.ptr, stat.data(), stat.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->mov.ptr, mov.data(), mov.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->movy.ptr, movy.data(), movy.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->segs.ptr, segs.data(), segs.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->cold.ptr, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
   ctx->n_objects = n;
@@ -361,6 +387,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   tor::KParams p{};
   p.stat = (const double*)ctx->stat.ptr;
   p.mov = (const double*)ctx->mov.ptr;
+  p.movy = (const double*)ctx->movy.ptr;
   p.segs = (const double*)ctx->segs.ptr;
   p.cold = (const double*)ctx->cold.ptr;
   p.n_segs = ctx->n_segs;

@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned long long bcast_first_u64(unsigned long long
 // One ray/object discriminant, strict or fused.  Returns the sign-bit filter word: negative
 // (bit 31 set) iff disc has a clear sign bit (disc >= +0 or NaN+) and (half_b < 0 or c < 0),
 // a superset of the objects the reference's hit() can accept (both roots are <= 0 when
-// half_b >= 0 and c >= 0).
+// half_b >= 0 and c >= 0).  One v_bitop3_b32: f(a,b,c) = (a|b) & ~c  -> truth table 0x54.
 template <int ARITH>
 __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, double dx, double dy,
                                            double dz, double a, double cx, double cy, double cz,
@@ -79,41 +79,67 @@ __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, doub
     cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
     disc = fma_(hb, hb, -(a * cc));
   }
+#if __has_builtin(__builtin_amdgcn_bitop3_b32)
+  return (int)__builtin_amdgcn_bitop3_b32((unsigned)hi32(hb), (unsigned)hi32(cc), (unsigned)hi32(disc), 0x54);
+#else
   return (hi32(hb) | hi32(cc)) & ~hi32(disc);
+#endif
 }
 
-constexpr int kQCap = 32;   // candidate queue entries per lane (LDS, u32)
-constexpr int kUnroll = 8;  // objects per overflow check; hot arrays are padded to this
+constexpr int kQCap = 16;   // candidate-queue entries per lane (LDS, u32): (block << 8) | 8-bit mask
+constexpr int kBlock = 8;   // objects per queue entry; hot arrays are padded to this (= kPad)
+constexpr int kAccSlots = 16;  // per-wave LDS pixel-accumulator cache (TOR_SEED_SAMPLE)
+static_assert(kBlock == kPad, "hot-record padding must equal the candidate block size");
+
+// LDS per wave: queue (kQCap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag))
+constexpr int kWaveLdsBytes = kQCap * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4;
+static_assert(kWaveLdsBytes % 16 == 0, "keep LDS carve-outs 16-byte aligned");
+
+// m = (m << 1) | (t >> 31) in one v_alignbit_b32
+__device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
+  return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
+}
 
 template <int SEEDING, int ARITH>
-__global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
+__global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned* smem = reinterpret_cast<unsigned*>(smem_raw);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  unsigned* q = smem + wave * (kQCap * 64) + lane;  // q[k * 64]: k-th candidate of this lane
+  unsigned char* wave_lds = smem_raw + wave * kWaveLdsBytes;
+  unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
+  double* acc_lds = reinterpret_cast<double*>(wave_lds + kQCap * 64 * 4);          // [kAccSlots][3]
+  int* tag_lds = reinterpret_cast<int*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 24);  // [kAccSlots]
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
+  const cdptr movy = as_const(p.movy);
   const cdptr segs = as_const(p.segs);
   const Camera cam = p.cam;
-  const double inv_w = (double)(p.ncols - 1);  // render.nim:64 divides by float64(ncols-1)
-  const double inv_h = (double)(p.nrows - 1);
+  const double w_div = (double)(p.ncols - 1);  // render.nim:64 divides by float64(ncols-1)
+  const double h_div = (double)(p.nrows - 1);
+
+  if (SEEDING == 1) {
+    if (lane < kAccSlots) {
+      tag_lds[lane] = -1;
+      acc_lds[lane * 3 + 0] = 0.0; acc_lds[lane * 3 + 1] = 0.0; acc_lds[lane * 3 + 2] = 0.0;
+    }
+  }
 
   // ---- lane state ------------------------------------------------------------------
   bool active = false;     // owns a live path
-  bool have_item = false;  // SEED_PIXEL: owns a pixel with samples left
+  bool have_item = false;  // owns a work item whose camera ray has not been generated yet
   V3 o = v3(0, 0, 0), d = v3(0, 0, 1), att = v3(1, 1, 1);
   double time = 0.0;
   Rng rng{0, 0, 0, 0};
   int depth = 0;
   int row = 0, col = 0, s = 0;
-  long long pix = -1;       // index into p.out (local pixel)
-  V3 acc = v3(0, 0, 0);     // SEED_PIXEL: pixel sum; SEED_SAMPLE: partial sum for acc_pix
-  long long acc_pix = -1;
+  int pix = -1;             // index into p.out (local pixel)
+  V3 acc = v3(0, 0, 0);     // SEED_PIXEL: the pixel's sum, in sample order
 
-  // ---- wave-uniform work range ---------------------------------------------------------
+  // ---- wave-uniform work range: [w_next, w_end) of the global index space; (cur_pl, cur_s)
+  //      is the (local pixel, sample) of w_next --------------------------------------------
   unsigned long long w_next = 0, w_end = 0;
+  unsigned cur_pl = 0, cur_s = 0;
   bool exhausted = false;
   unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
 
@@ -123,55 +149,71 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
     unsigned long long need_mask = ballot64(need_fetch);
     if (need_mask != 0) {
       if (w_next >= w_end && !exhausted) {
+        const int leader = (int)__builtin_ctzll(need_mask);
         unsigned long long base = 0;
-        if (lane == (int)__builtin_ctzll(need_mask)) base = atomicAdd(p.work_counter, (unsigned long long)p.chunk);
-        base = bcast_first_u64(__shfl(base, (int)__builtin_ctzll(need_mask)));
+        if (lane == leader) base = atomicAdd(p.work_counter, (unsigned long long)p.chunk);
+        base = bcast_first_u64(__shfl(base, leader));
         if (base >= p.total_work) {
           exhausted = true;
         } else {
           w_next = base;
           w_end = (base + p.chunk < p.total_work) ? base + p.chunk : p.total_work;
+          if (SEEDING == 0) {
+            cur_pl = (unsigned)base;
+            cur_s = 0;
+          } else {  // one 64-bit division per chunk, wave-uniform
+            unsigned long long pl0 = base / (unsigned)p.spp;
+            cur_pl = (unsigned)pl0;
+            cur_s = (unsigned)(base - pl0 * (unsigned)p.spp);
+          }
         }
       }
       if (w_next < w_end) {
-        unsigned prefix = lane_prefix(need_mask);
-        unsigned long long idx = w_next + prefix;
-        bool got = need_fetch && idx < w_end;
-        unsigned long long avail = w_end - w_next;
-        unsigned long long want = (unsigned long long)__builtin_popcountll(need_mask);
-        w_next += (want < avail) ? want : avail;
+        const unsigned prefix = lane_prefix(need_mask);
+        const unsigned avail = (unsigned)(w_end - w_next);
+        const unsigned want = (unsigned)__builtin_popcountll(need_mask);
+        const unsigned take = (want < avail) ? want : avail;
+        const bool got = need_fetch && prefix < take;
         if (got) {
-          // work index -> (local pixel, sample)
-          unsigned long long pl;
+          unsigned pl;
           if (SEEDING == 0) {
-            pl = idx;
+            pl = cur_pl + prefix;
             s = 0;
             acc = v3(0, 0, 0);
           } else {
-            pl = idx / (unsigned)p.spp;
-            s = (int)(idx - pl * (unsigned)p.spp);
+            const unsigned t = cur_s + prefix;
+            const unsigned dp = t / (unsigned)p.spp;
+            pl = cur_pl + dp;
+            s = (int)(t - dp * (unsigned)p.spp);
           }
-          unsigned lrow = (unsigned)(pl / (unsigned)p.ncols);
-          col = (int)(pl - (unsigned long long)lrow * (unsigned)p.ncols);
+          const unsigned lrow = pl / (unsigned)p.ncols;
+          col = (int)(pl - lrow * (unsigned)p.ncols);
           // local row -> image row (tiles of row_tile rows dealt round-robin to the shards)
-          unsigned tile = lrow / (unsigned)p.row_tile;
-          unsigned within = lrow - tile * (unsigned)p.row_tile;
+          const unsigned tile = lrow / (unsigned)p.row_tile;
+          const unsigned within = lrow - tile * (unsigned)p.row_tile;
           row = (int)((tile * (unsigned)p.shard_count + (unsigned)p.shard_index) * (unsigned)p.row_tile + within);
-          pix = (long long)pl;
+          pix = (int)pl;
           have_item = true;
           if (SEEDING == 0) seed2(rng, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);  // render.nim:59-60
+        }
+        w_next += take;
+        if (SEEDING == 0) {
+          cur_pl += take;
+        } else {
+          const unsigned t = cur_s + take;
+          const unsigned dp = t / (unsigned)p.spp;
+          cur_pl += dp;
+          cur_s = t - dp * (unsigned)p.spp;
         }
       }
     }
     if (!active && have_item) {
-      if (SEEDING == 1) {
-        seed3(rng, (uint64_t)row, (uint64_t)col, (uint64_t)s);
-        have_item = false;  // a sample item is consumed by starting it
-      }
+      if (SEEDING == 1) seed3(rng, (uint64_t)row, (uint64_t)col, (uint64_t)s);
+      have_item = false;  // the pending sample is consumed by starting its path
       // render.nim:64-66
-      double u = ((double)col + uniform01(rng)) / inv_w;
-      double v = ((double)row + uniform01(rng)) / inv_h;
-      Ray r = camera_ray(cam, u, v, rng);
+      const double u = ((double)col + uniform01(rng)) / w_div;
+      const double v = ((double)row + uniform01(rng)) / h_div;
+      const Ray r = camera_ray(cam, u, v, rng);
       o = r.origin;
       d = r.direction;
       time = r.time;
@@ -179,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
       depth = 0;
       active = true;
     }
-    unsigned long long active_mask = ballot64(active);
+    const unsigned long long active_mask = ballot64(active);
     if (active_mask == 0) {
       if (exhausted) break;
       continue;
@@ -187,6 +229,8 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
     st_iters += 1;
     st_queries += (unsigned long long)__builtin_popcountll(active_mask);
 
+    bool ended = false;
+    V3 radiance = v3(0.0, 0.0, 0.0);
     if (active) {
       // ================= (B) closest hit over all objects ==============================
       // hittables_lists.nim:48-55 with t_min = 0.001, t_max = Inf (render.nim:28)
@@ -205,44 +249,63 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
         bool full = false;
         while (seg < p.n_segs) {
           const int seg_kind = (int)segs[seg * 8 + 0];
-          const int seg_begin = (int)segs[seg * 8 + 1];   // first hot record / first sorted index
-          const int seg_count = (int)segs[seg * 8 + 2];   // padded to kUnroll
-          const int seg_sorted0 = (int)segs[seg * 8 + 3]; // sorted index of record 0
+          const int seg_begin = (int)segs[seg * 8 + 1];    // first hot record of the segment
+          const int seg_count = (int)segs[seg * 8 + 2];    // padded to kBlock
+          const int seg_block0 = (int)segs[seg * 8 + 3];   // (first sorted index) / kBlock
           if (seg_kind == 0) {
-            for (; i < seg_count; i += kUnroll) {
+            for (; i < seg_count; i += kBlock) {
+              unsigned m = 0;
 #pragma unroll
-              for (int j = 0; j < kUnroll; ++j) {
+              for (int j = 0; j < kBlock; ++j) {
                 const int k = seg_begin + i + j;
-                const double cx = stat[4 * k + 0], cy = stat[4 * k + 1], cz = stat[4 * k + 2];
-                const double r2 = stat[4 * k + 3];
-                int t = disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, r2);
-                q[qn * 64] = (unsigned)(seg_sorted0 + i + j);
-                qn += (unsigned)t >> 31;
+                m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, stat[4 * k + 0], stat[4 * k + 1],
+                                                   stat[4 * k + 2], stat[4 * k + 3]));
               }
-              if (ballot64(qn > (unsigned)(kQCap - kUnroll)) != 0) { full = true; i += kUnroll; break; }
+              q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+              qn += (m != 0) ? 1u : 0u;
+              if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
             }
           } else {
             // moving_spheres.nim:39-44: f = (time - time0) / (time1 - time0)
             const double t0 = segs[seg * 8 + 4], dt = segs[seg * 8 + 5];
             const double f = (time - t0) / dt;
-            for (; i < seg_count; i += kUnroll) {
+            if (seg_kind == 1) {
+              // every sphere of the segment moves along y only (center1.x == center0.x and
+              // center1.z == center0.z): c0 + f*0 == c0 exactly, so x and z need no arithmetic
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
 #pragma unroll
-              for (int j = 0; j < kUnroll; ++j) {
-                const int k = seg_begin + i + j;
-                const double c0x = mov[8 * k + 0], c0y = mov[8 * k + 1], c0z = mov[8 * k + 2];
-                const double r2 = mov[8 * k + 3];
-                const double dcx = mov[8 * k + 4], dcy = mov[8 * k + 5], dcz = mov[8 * k + 6];
-                double cx, cy, cz;
-                if (ARITH == 0) {
-                  cx = c0x + dcx * f; cy = c0y + dcy * f; cz = c0z + dcz * f;
-                } else {
-                  cx = fma_(dcx, f, c0x); cy = fma_(dcy, f, c0y); cz = fma_(dcz, f, c0z);
+                for (int j = 0; j < kBlock; ++j) {
+                  const int k = seg_begin + i + j;
+                  const double c0y = movy[6 * k + 1], dcy = movy[6 * k + 4];
+                  const double cy = (ARITH == 0) ? c0y + dcy * f : fma_(dcy, f, c0y);
+                  m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, movy[6 * k + 0], cy,
+                                                     movy[6 * k + 2], movy[6 * k + 3]));
                 }
-                int t = disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, r2);
-                q[qn * 64] = (unsigned)(seg_sorted0 + i + j);
-                qn += (unsigned)t >> 31;
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
               }
-              if (ballot64(qn > (unsigned)(kQCap - kUnroll)) != 0) { full = true; i += kUnroll; break; }
+            } else {
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock; ++j) {
+                  const int k = seg_begin + i + j;
+                  const double c0x = mov[8 * k + 0], c0y = mov[8 * k + 1], c0z = mov[8 * k + 2];
+                  const double dcx = mov[8 * k + 4], dcy = mov[8 * k + 5], dcz = mov[8 * k + 6];
+                  double cx, cy, cz;
+                  if (ARITH == 0) {
+                    cx = c0x + dcx * f; cy = c0y + dcy * f; cz = c0z + dcz * f;
+                  } else {
+                    cx = fma_(dcx, f, c0x); cy = fma_(dcy, f, c0y); cz = fma_(dcz, f, c0z);
+                  }
+                  m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, mov[8 * k + 3]));
+                }
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
             }
           }
           if (full) break;
@@ -251,10 +314,21 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
         }
 
         // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
-        st_cand += (unsigned long long)qn;  // per-lane; reduced at the end
-        for (unsigned k = 0; ballot64(k < qn) != 0; ++k) {
-          if (k < qn) {
-            const unsigned idx = q[k * 64];
+        unsigned kq = 0, cur_mask = 0, cur_block = 0;
+        for (;;) {
+          if (cur_mask == 0 && kq < qn) {
+            const unsigned e = q[kq * 64];
+            kq += 1;
+            cur_block = e >> 8;
+            cur_mask = e & 0xffu;
+          }
+          const bool has = cur_mask != 0;
+          if (ballot64(has) == 0) break;
+          if (has) {
+            const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> object j of the block
+            cur_mask &= ~(1u << b);
+            const unsigned idx = cur_block * kBlock + (unsigned)(7 - b);
+            st_cand += 1;
             const double* c = p.cold + (size_t)idx * 16;
             const double c0x = c[0], c0y = c[1], c0z = c[2];
             const double r2 = c[15];
@@ -268,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
                 cx = fma_(c[3], f, c0x); cy = fma_(c[4], f, c0y); cz = fma_(c[5], f, c0z);
               }
             }
-            double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+            const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
             double hb, cc, disc;
             if (ARITH == 0) {
               hb = ocx * dx + ocy * dy + ocz * dz;
@@ -303,8 +377,6 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
       }
 
       // ================= (C) shade ====================================================
-      bool ended = false;
-      V3 radiance = v3(0.0, 0.0, 0.0);
       if (best_idx < 0) {
         radiance = sky(d, att);  // render.nim:41-45
         ended = true;
@@ -327,8 +399,8 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
           o = hp;
           att = mul_att(att, albedo);  // render.nim:35
         } else if (mat == kMetal) {  // materials.nim:39-47
-          V3 reflected = reflect(unit_vector(d), n);
-          V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
+          const V3 reflected = reflect(unit_vector(d), n);
+          const V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
           o = hp;
           d = nd;
           time = 0.0;  // rays.nim:19 default
@@ -372,33 +444,54 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(const KParams p) {
           if (s >= p.spp) {
             double* out = p.out + (size_t)pix * 3;
             out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
-            have_item = false;
+          } else {
+            have_item = true;  // next sample of the same pixel, same stream
           }
-        } else {
-          if (acc_pix != pix) {
-            if (acc_pix >= 0) {
-              double* out = p.out + (size_t)acc_pix * 3;
-              unsafeAtomicAdd(out + 0, acc.x);
-              unsafeAtomicAdd(out + 1, acc.y);
-              unsafeAtomicAdd(out + 2, acc.z);
-            }
-            acc = v3(0, 0, 0);
-            acc_pix = pix;
-          }
-          acc = acc + v3(quantize36(radiance.x), quantize36(radiance.y), quantize36(radiance.z));
         }
+      }
+    }
+
+    if (SEEDING == 1) {
+      // ---- deposit finished samples: exact (2^-36-quantised) float64 sums, any order ------
+      // The wave keeps the pixels it is currently filling in a small LDS cache (pixels arrive
+      // in increasing order, so a slot is evicted when the pixel is complete bar stragglers);
+      // HBM only sees one flush per pixel and wave instead of one atomic per sample.
+      unsigned long long ended_mask = ballot64(ended);
+      const double qx = quantize36(radiance.x), qy = quantize36(radiance.y), qz = quantize36(radiance.z);
+      while (ended_mask != 0) {
+        const int src = (int)__builtin_ctzll(ended_mask);
+        const int pp = __builtin_amdgcn_readlane(pix, src);
+        const bool mine = ended && pix == pp;
+        const int slot = pp & (kAccSlots - 1);
+        const int tag = __builtin_amdgcn_readfirstlane(tag_lds[slot]);
+        if (tag != pp) {
+          if (lane < 3) {
+            if (tag >= 0) unsafeAtomicAdd(p.out + (size_t)tag * 3 + lane, acc_lds[slot * 3 + lane]);
+            acc_lds[slot * 3 + lane] = 0.0;
+          }
+          if (lane == 0) tag_lds[slot] = pp;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+        if (mine) {
+          unsafeAtomicAdd(&acc_lds[slot * 3 + 0], qx);
+          unsafeAtomicAdd(&acc_lds[slot * 3 + 1], qy);
+          unsafeAtomicAdd(&acc_lds[slot * 3 + 2], qz);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        ended_mask &= ~ballot64(mine);
       }
     }
   }
 
-  if (SEEDING == 1 && acc_pix >= 0) {
-    double* out = p.out + (size_t)acc_pix * 3;
-    unsafeAtomicAdd(out + 0, acc.x);
-    unsafeAtomicAdd(out + 1, acc.y);
-    unsafeAtomicAdd(out + 2, acc.z);
+  if (SEEDING == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < kAccSlots * 3) {
+      const int slot = lane / 3, ch = lane - slot * 3;
+      const int tag = tag_lds[slot];
+      if (tag >= 0) unsafeAtomicAdd(p.out + (size_t)tag * 3 + ch, acc_lds[slot * 3 + ch]);
+    }
   }
   if (p.stats != nullptr) {
-    // per-lane counters -> wave sums
     unsigned long long cand = st_cand, smp = st_samples;
     for (int off = 32; off > 0; off >>= 1) {
       cand += __shfl_xor(cand, off);
@@ -441,7 +534,7 @@ __global__ void selftest_kernel(int op, const double* x, const double* y, double
 // host-side launchers (called from tor_api.cpp)
 // ---------------------------------------------------------------------------------------
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream) {
-  const size_t smem = (size_t)kQCap * 64 * sizeof(unsigned) * (kThreads / 64);
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
   dim3 grid((unsigned)blocks), block(kThreads);
   if (seeding == 0 && arith == 0) hipLaunchKernelGGL((integrate_kernel<0, 0>), grid, block, smem, stream, p);
   else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1>), grid, block, smem, stream, p);
@@ -451,7 +544,7 @@ hipError_t launch_integrate(const KParams& p, int seeding, int arith, int blocks
 }
 
 int integrate_blocks_per_cu(int seeding, int arith) {
-  const size_t smem = (size_t)kQCap * 64 * sizeof(unsigned) * (kThreads / 64);
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
   int n = 0;
   hipError_t e;
   if (seeding == 0 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 0>, kThreads, smem);

@@ -17,14 +17,17 @@ constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of 
 //   stat : static spheres, 4 float64 each   {cx, cy, cz, radius^2}
 //   mov  : moving spheres, 8 float64 each   {c0x, c0y, c0z, radius^2, dcx, dcy, dcz, 0}
 //          with dc = center1 - center0, grouped by (time0, time1)
-//   segs : 8 float64 per segment {kind (0 static, 1 moving), first record, padded count,
-//          first sorted index, time0, time1 - time0, 0, 0}
+//   movy : moving spheres of groups that move along y only, 6 float64 each
+//          {c0x, c0y, c0z, radius^2, dcy, 0}
+//   segs : 8 float64 per segment {kind (0 static, 1 moving along y only, 2 moving), first
+//          record, padded count, (first sorted index)/kPad, time0, time1 - time0, 0, 0}
 //   cold : 16 float64 per sorted slot {c0 xyz, dc xyz, 1/radius, time0, time1-time0,
 //          albedo xyz, fuzz|refraction_index, flags(bit0 moving, bits 8..15 material kind),
 //          original index, radius^2}; flags/original index are int64 bit patterns.
 struct KParams {
   const double* stat;
   const double* mov;
+  const double* movy;
   const double* segs;
   const double* cold;
   int n_segs;
