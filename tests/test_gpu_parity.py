@@ -207,3 +207,25 @@ def test_full_size_properties(tor):
     ms, n = ctx.last_kernel_ms()
     assert n == (h // 4 + 0) * 0 + len(tor.shard_rows(h, 8, 3, 4)) * w * spp and ms > 0
     ctx.close()
+
+
+def test_host_canvas_rate(tor):
+    """tor_render_opt on host buffers (what a Nim caller pays: scene upload + kernel + sync + D2H of
+    the canvas).  Records the PCIe-inclusive rate next to the resident-buffer rate in
+    gpurun_out/host_canvas_rate.json; it is never the bench value."""
+    import json
+    import time
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    h, w, spp = 1080, 1920, 20
+    opt = tor.make_options(seeding=tor.SEED_SAMPLE)
+    cv = tor.new_canvas(h, w, spp, 2.2)
+    tor.render(cv, cam, scene.list(), 50, opt)  # warm-up: context creation, first launch
+    t = time.perf_counter()
+    tor.render(cv, cam, scene.list(), 50, opt)
+    dt = time.perf_counter() - t
+    rate = h * w * spp / dt / 1e6
+    assert np.all(np.isfinite(cv.pixels)) and rate > 50.0
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "host_canvas_rate.json"), "w") as f:
+            json.dump({"workload": f"{w}x{h}x{spp}spp", "seconds": dt, "msamples_per_s_pcie_inclusive": rate}, f)
