@@ -119,7 +119,7 @@ assert C.sizeof(HittableList) == 16 and C.sizeof(Camera) == 192 and C.sizeof(Can
 EXPORTED_SYMBOLS = [
     "tor_render", "tor_render_opt", "tor_last_error", "tor_context_create", "tor_context_destroy",
     "tor_scene_upload", "tor_shard_rows", "tor_render_device", "tor_quantize_rgb8_device",
-    "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_camera_init",
+    "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
@@ -173,6 +173,7 @@ def lib():
     L.tor_kernel_ms_mean.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.tor_context_set_stats.argtypes = [C.c_void_p, C.c_int32]
     L.tor_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.tor_last_wave_log.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
     L.tor_camera_init.argtypes = [C.POINTER(Camera), C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Vec3)] + \
                                  [C.c_double] * 6
     L.tor_random_scene.argtypes = [C.c_uint64, C.POINTER(HittableVariant), C.c_int64]
@@ -393,6 +394,13 @@ class Context:
         n = C.c_int32(0)
         _check(lib().tor_kernel_ms_mean(self._h, last_n, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def last_wave_log(self, cap_waves: int = 16384) -> np.ndarray:
+        buf = np.zeros((cap_waves, 8), dtype=np.uint64)
+        n = lib().tor_last_wave_log(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap_waves)
+        if n < 0:
+            _check(n)
+        return buf[:n]
 
     def last_stats(self) -> Stats:
         st = Stats()

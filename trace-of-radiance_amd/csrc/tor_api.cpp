@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -84,6 +85,8 @@ struct TorContext {
   bool scene_ready = false;
   // work
   DeviceBuffer counters;  // [0] work counter, [1..4] stats
+  DeviceBuffer wave_log;  // debug: 4 x u64 per wave (only with stats enabled)
+  DeviceBuffer cam_ring;  // 64 x TorCamera: one slot per in-flight launch (async-safe)
   DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
   bool collect_stats = false;
   static constexpr int kEventRing = 64;
@@ -91,7 +94,17 @@ struct TorContext {
   int64_t launches = 0;  // timed integrator launches so far
   bool timing_valid = false;
   int64_t last_samples = 0;
+  int64_t last_n_waves = 0;
   int blocks_per_cu[2][2] = {{0, 0}, {0, 0}};
+  // Launch shape, measured on MI355X (profiles/r1_wave_service.txt): waves that share a SIMD get
+  // very unequal service (hardware slot 0 ~38 us per bounce iteration, slot 4 0.6-2 ms), so
+  // extra waves add little throughput and park work in slow waves.  Per seeding mode:
+  //   SAMPLE: 128-VGPR kernel (no spills), 3 workgroups/CU  -> best throughput
+  //   PIXEL : 2 workgroups/CU: a pixel is a sequential chain of spp samples, every wave that
+  //           holds one must get good service
+  // Overridable for experiments: TOR_WAVES_PER_SIMD (4|5), TOR_BLOCKS_PER_CU.
+  int max_blocks_per_cu[2] = {2, 3};  // [seeding]
+  int waves_per_simd = 4;  // register budget variant of the integrator (4: 128 VGPR, 5: 96 VGPR)
 };
 
 namespace {
@@ -153,7 +166,10 @@ int tor_context_create(int32_t device, TorContext** out) {
     return fail_hip(e, "hipGetDeviceProperties");
   }
   ctx->num_cus = prop.multiProcessorCount;
+  if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_per_simd = (std::atoi(w) >= 5) ? 5 : 4;
+  if (const char* b = std::getenv("TOR_BLOCKS_PER_CU")) ctx->max_blocks_per_cu[0] = ctx->max_blocks_per_cu[1] = std::atoi(b);
   e = ctx->counters.ensure(8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kEventRing * sizeof(TorCamera));
   for (int i = 0; i < TorContext::kEventRing && e == hipSuccess; ++i) {
     e = hipEventCreate(&ctx->ev_start[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop[i]);
@@ -175,6 +191,8 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->segs.release();
   ctx->cold.release();
   ctx->counters.release();
+  ctx->cam_ring.release();
+  ctx->wave_log.release();
   ctx->scratch.release();
   for (int i = 0; i < TorContext::kEventRing; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
@@ -381,7 +399,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
   int& bpc = ctx->blocks_per_cu[o.seeding][o.arith];
-  if (bpc == 0) bpc = tor::integrate_blocks_per_cu(o.seeding, o.arith);
+  if (bpc == 0) bpc = tor::integrate_blocks_per_cu(o.seeding, o.arith, ctx->waves_per_simd);
+  if (ctx->max_blocks_per_cu[o.seeding] > 0 && bpc > ctx->max_blocks_per_cu[o.seeding]) bpc = ctx->max_blocks_per_cu[o.seeding];
   const long long resident_waves = (long long)ctx->num_cus * bpc * (tor::kThreads / 64);
 
   tor::KParams p{};
@@ -396,7 +415,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.work_counter = (unsigned long long*)ctx->counters.ptr;
   p.stats = ctx->collect_stats ? (unsigned long long*)ctx->counters.ptr + 1 : nullptr;
   p.out = d_pixels;
-  std::memcpy(&p.cam, cam, sizeof(TorCamera));
 
   long long waves;
   if (o.seeding == TOR_SEED_PIXEL) {
@@ -407,17 +425,29 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.total_work = (unsigned long long)npix * (unsigned long long)spp;
     long long c = (long long)(p.total_work / (unsigned long long)(resident_waves * 16));
     if (c < 64) c = 64;
-    if (c > 16384) c = 16384;
+    if (c > 1024) c = 1024;
     p.chunk = (unsigned)(c / 64 * 64);
     waves = (long long)((p.total_work + 63) / 64);
   }
   if (waves > resident_waves) waves = resident_waves;
   int blocks = (int)((waves + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
   if (blocks < 1) blocks = 1;
+  p.n_waves = (unsigned)(blocks * (tor::kThreads / 64));
+  p.wave_log = nullptr;
+  if (ctx->collect_stats) {
+    HIP_TRY(ctx->wave_log.ensure((size_t)p.n_waves * 64));
+    HIP_TRY(hipMemsetAsync(ctx->wave_log.ptr, 0, (size_t)p.n_waves * 64, stream));
+    p.wave_log = (unsigned long long*)ctx->wave_log.ptr;
+    ctx->last_n_waves = (int64_t)p.n_waves;
+  }
 
   const int slot = (int)(ctx->launches % TorContext::kEventRing);
+  // the camera travels in its own small device slot (one per in-flight launch; a slot is reused
+  // only after 64 further launches on this context)
+  p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
+  HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, cam, sizeof(TorCamera), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
-  HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, blocks, stream));
+  HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, ctx->waves_per_simd, blocks, stream));
   HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
   ctx->launches += 1;
   ctx->timing_valid = true;
@@ -467,6 +497,16 @@ int tor_kernel_ms_mean(TorContext* ctx, int32_t last_n, float* mean_ms_out, int3
   *mean_ms_out = (float)(sum / (double)n);
   if (n_used_out) *n_used_out = (int32_t)n;
   return TOR_OK;
+}
+
+int tor_last_wave_log(TorContext* ctx, uint64_t* out, int64_t cap_waves) {
+  if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_wave_log: NULL argument");
+  if (!ctx->collect_stats || ctx->last_n_waves <= 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_wave_log: stats not enabled");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t n = ctx->last_n_waves < cap_waves ? ctx->last_n_waves : cap_waves;
+  HIP_TRY(hipMemcpy(out, ctx->wave_log.ptr, (size_t)n * 64, hipMemcpyDeviceToHost));
+  return (int)n;
 }
 
 int tor_last_stats(TorContext* ctx, TorStats* out) {

@@ -95,13 +95,34 @@ static_assert(kBlock == kPad, "hot-record padding must equal the candidate block
 constexpr int kWaveLdsBytes = kQCap * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4;
 static_assert(kWaveLdsBytes % 16 == 0, "keep LDS carve-outs 16-byte aligned");
 
+// The camera (24 float64) is needed once per new path only; read it there instead of keeping
+// it in 48 SGPRs across the object loop.  The empty asm makes the pointer opaque per call so
+// the loads are not hoisted out of the bounce loop.
+__device__ __forceinline__ Camera load_camera(const double* cam_dev) {
+  const double* pc = cam_dev;
+  asm volatile("" : "+s"(pc));
+  cdptr c = as_const(pc);
+  Camera cam;
+  cam.origin = v3(c[0], c[1], c[2]);
+  cam.lower_left_corner = v3(c[3], c[4], c[5]);
+  cam.horizontal = v3(c[6], c[7], c[8]);
+  cam.vertical = v3(c[9], c[10], c[11]);
+  cam.u = v3(c[12], c[13], c[14]);
+  cam.v = v3(c[15], c[16], c[17]);
+  cam.w = v3(c[18], c[19], c[20]);
+  cam.lens_radius = c[21];
+  cam.shutter_open = c[22];
+  cam.shutter_close = c[23];
+  return cam;
+}
+
 // m = (m << 1) | (t >> 31) in one v_alignbit_b32
 __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
   return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
 }
 
-template <int SEEDING, int ARITH>
-__global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p) {
+template <int SEEDING, int ARITH, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -114,7 +135,6 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
   const cdptr mov = as_const(p.mov);
   const cdptr movy = as_const(p.movy);
   const cdptr segs = as_const(p.segs);
-  const Camera cam = p.cam;
   const double w_div = (double)(p.ncols - 1);  // render.nim:64 divides by float64(ncols-1)
   const double h_div = (double)(p.nrows - 1);
 
@@ -140,8 +160,11 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
   //      is the (local pixel, sample) of w_next --------------------------------------------
   unsigned long long w_next = 0, w_end = 0;
   unsigned cur_pl = 0, cur_s = 0;
+  unsigned next_chunk = p.chunk;
   bool exhausted = false;
   unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
+  const unsigned long long t_start = (p.wave_log != nullptr) ? wall_clock64() : 0ull;
+  unsigned long long t_exh = 0, it_exh = 0;
 
   for (;;) {
     // ================= (A) refill lanes that have no live path =========================
@@ -150,14 +173,20 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
     if (need_mask != 0) {
       if (w_next >= w_end && !exhausted) {
         const int leader = (int)__builtin_ctzll(need_mask);
+        // SEED_PIXEL: tiles of p.chunk consecutive pixels (neighbouring pixels in one wave keep the
+        // rays coherent).  SEED_SAMPLE: guided self-scheduling, the chunk shrinks with the work
+        // that is left (waves of one SIMD get very unequal service -- slot 0 runs ~20x faster than
+        // slot 4 -- so anything parked in a slow wave becomes the tail of the frame).
+        const unsigned grab = (SEEDING == 0) ? p.chunk : next_chunk;
         unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(p.work_counter, (unsigned long long)p.chunk);
+        if (lane == leader) base = atomicAdd(p.work_counter, (unsigned long long)grab);
         base = bcast_first_u64(__shfl(base, leader));
         if (base >= p.total_work) {
           exhausted = true;
+          if (p.wave_log != nullptr) { t_exh = wall_clock64(); it_exh = st_iters; }
         } else {
           w_next = base;
-          w_end = (base + p.chunk < p.total_work) ? base + p.chunk : p.total_work;
+          w_end = (base + grab < p.total_work) ? base + grab : p.total_work;
           if (SEEDING == 0) {
             cur_pl = (unsigned)base;
             cur_s = 0;
@@ -165,6 +194,10 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
             unsigned long long pl0 = base / (unsigned)p.spp;
             cur_pl = (unsigned)pl0;
             cur_s = (unsigned)(base - pl0 * (unsigned)p.spp);
+            const unsigned long long left = p.total_work - w_end;
+            unsigned long long g = left / ((unsigned long long)p.n_waves * 32ull);
+            g = (g > p.chunk) ? p.chunk : g;
+            next_chunk = (g < 64) ? 64u : (unsigned)g;
           }
         }
       }
@@ -213,6 +246,7 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
       // render.nim:64-66
       const double u = ((double)col + uniform01(rng)) / w_div;
       const double v = ((double)row + uniform01(rng)) / h_div;
+      const Camera cam = load_camera(p.cam_dev);
       const Ray r = camera_ray(cam, u, v, rng);
       o = r.origin;
       d = r.direction;
@@ -228,7 +262,6 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
     }
     st_iters += 1;
     st_queries += (unsigned long long)__builtin_popcountll(active_mask);
-
     bool ended = false;
     V3 radiance = v3(0.0, 0.0, 0.0);
     if (active) {
@@ -253,14 +286,20 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
           const int seg_count = (int)segs[seg * 8 + 2];    // padded to kBlock
           const int seg_block0 = (int)segs[seg * 8 + 3];   // (first sorted index) / kBlock
           if (seg_kind == 0) {
+            // one base pointer per block, immediate offsets inside it, and the next record is
+            // requested one object ahead of its use (s_load latency hides under ~17 VALU ops)
+            cdptr rec = stat + 4 * (long)(seg_begin + i);
+            double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
             for (; i < seg_count; i += kBlock) {
               unsigned m = 0;
 #pragma unroll
               for (int j = 0; j < kBlock; ++j) {
-                const int k = seg_begin + i + j;
-                m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, stat[4 * k + 0], stat[4 * k + 1],
-                                                   stat[4 * k + 2], stat[4 * k + 3]));
+                const double c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+                n0 = rec[4 * (j + 1) + 0]; n1 = rec[4 * (j + 1) + 1];   // next object (the arrays carry one
+                n2 = rec[4 * (j + 1) + 2]; n3 = rec[4 * (j + 1) + 3];   // record of slack past the last block)
+                m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0, c1, c2, c3));
               }
+              rec += 4 * kBlock;
               q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
@@ -272,16 +311,19 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
             if (seg_kind == 1) {
               // every sphere of the segment moves along y only (center1.x == center0.x and
               // center1.z == center0.z): c0 + f*0 == c0 exactly, so x and z need no arithmetic
+              cdptr rec = movy + 6 * (long)(seg_begin + i);
+              double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
               for (; i < seg_count; i += kBlock) {
                 unsigned m = 0;
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j) {
-                  const int k = seg_begin + i + j;
-                  const double c0y = movy[6 * k + 1], dcy = movy[6 * k + 4];
+                  const double c0x = n0, c0y = n1, c0z = n2, r2 = n3, dcy = n4;
+                  n0 = rec[6 * (j + 1) + 0]; n1 = rec[6 * (j + 1) + 1]; n2 = rec[6 * (j + 1) + 2];
+                  n3 = rec[6 * (j + 1) + 3]; n4 = rec[6 * (j + 1) + 4];
                   const double cy = (ARITH == 0) ? c0y + dcy * f : fma_(dcy, f, c0y);
-                  m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, movy[6 * k + 0], cy,
-                                                     movy[6 * k + 2], movy[6 * k + 3]));
+                  m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0x, cy, c0z, r2));
                 }
+                rec += 6 * kBlock;
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
@@ -497,6 +539,12 @@ __global__ __launch_bounds__(kThreads, 4) void integrate_kernel(const KParams p)
       cand += __shfl_xor(cand, off);
       smp += __shfl_xor(smp, off);
     }
+    if (lane == 0 && p.wave_log != nullptr) {
+      unsigned long long* w = p.wave_log + (size_t)(blockIdx.x * (kThreads / 64) + wave) * 8;
+      w[0] = t_start; w[1] = wall_clock64(); w[2] = st_iters;
+      w[3] = st_queries | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
+      w[4] = t_exh; w[5] = it_exh; w[6] = 0; w[7] = 0;
+    }
     if (lane == 0) {
       atomicAdd(p.stats + 0, st_queries);
       atomicAdd(p.stats + 1, cand);
@@ -533,26 +581,38 @@ __global__ void selftest_kernel(int op, const double* x, const double* y, double
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from tor_api.cpp)
 // ---------------------------------------------------------------------------------------
-hipError_t launch_integrate(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream) {
+template <int W>
+static hipError_t launch_integrate_w(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream) {
   const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
   dim3 grid((unsigned)blocks), block(kThreads);
-  if (seeding == 0 && arith == 0) hipLaunchKernelGGL((integrate_kernel<0, 0>), grid, block, smem, stream, p);
-  else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1>), grid, block, smem, stream, p);
-  else if (seeding == 1 && arith == 0) hipLaunchKernelGGL((integrate_kernel<1, 0>), grid, block, smem, stream, p);
-  else hipLaunchKernelGGL((integrate_kernel<1, 1>), grid, block, smem, stream, p);
+  if (seeding == 0 && arith == 0) hipLaunchKernelGGL((integrate_kernel<0, 0, W>), grid, block, smem, stream, p);
+  else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1, W>), grid, block, smem, stream, p);
+  else if (seeding == 1 && arith == 0) hipLaunchKernelGGL((integrate_kernel<1, 0, W>), grid, block, smem, stream, p);
+  else hipLaunchKernelGGL((integrate_kernel<1, 1, W>), grid, block, smem, stream, p);
   return hipGetLastError();
 }
 
-int integrate_blocks_per_cu(int seeding, int arith) {
+hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
+                            hipStream_t stream) {
+  if (waves_per_simd >= 5) return launch_integrate_w<5>(p, seeding, arith, blocks, stream);
+  return launch_integrate_w<4>(p, seeding, arith, blocks, stream);
+}
+
+template <int W>
+static int blocks_per_cu_w(int seeding, int arith) {
   const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
   int n = 0;
   hipError_t e;
-  if (seeding == 0 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 0>, kThreads, smem);
-  else if (seeding == 0 && arith == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 1>, kThreads, smem);
-  else if (seeding == 1 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 0>, kThreads, smem);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 1>, kThreads, smem);
+  if (seeding == 0 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 0, W>, kThreads, smem);
+  else if (seeding == 0 && arith == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 1, W>, kThreads, smem);
+  else if (seeding == 1 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 0, W>, kThreads, smem);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 1, W>, kThreads, smem);
   if (e != hipSuccess || n < 1) n = 1;
   return n;
+}
+
+int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd) {
+  return waves_per_simd >= 5 ? blocks_per_cu_w<5>(seeding, arith) : blocks_per_cu_w<4>(seeding, arith);
 }
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {

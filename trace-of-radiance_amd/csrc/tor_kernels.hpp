@@ -33,16 +33,19 @@ struct KParams {
   int n_segs;
   int nrows, ncols, spp, max_depth;
   int shard_index, shard_count, row_tile;
-  unsigned chunk;
+  unsigned chunk;   // SEED_SAMPLE: largest chunk of the guided schedule
+  unsigned n_waves; // waves launched
   unsigned long long total_work;
   unsigned long long* work_counter;
   double* out;
   unsigned long long* stats;  // nullable: {queries, candidates, wave iterations, samples}
-  Camera cam;
+  unsigned long long* wave_log;  // nullable (with stats): per wave {start, end (100 MHz clock), iterations, queries}
+  const double* cam_dev;  // 24 float64, TorCamera layout (cameras.nim:15-22)
 };
 
-hipError_t launch_integrate(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream);
-int integrate_blocks_per_cu(int seeding, int arith);
+hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
+                            hipStream_t stream);
+int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd);
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
 hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
