@@ -105,6 +105,29 @@ def test_c1_reference_image(tor, oracle, ref_scene, ref_camera, golden_dir):
     assert int(np.abs(rgb.astype(int) - g.astype(int)).max()) <= 8
 
 
+def test_pixel_seeding_cost_ordered_schedule(tor, oracle, ref_scene, ref_camera):
+    """spp >= 32 switches SEED_PIXEL to the probe + cost-ordered (LPT) tile schedule; the schedule must
+    never change a pixel.  37x45 = 1665 pixels = 26 tiles + a partial one."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = _render(tor, scene, cam, 37, 45, 32, seeding=tor.SEED_PIXEL)
+    want = oracle.render(37, 45, 32, ref_camera, objs, seeding=0, math=1, arith=0).pixels
+    _assert_parity(cv.pixels, want)
+    cv = _render(tor, scene, cam, 37, 45, 33, seeding=tor.SEED_PIXEL, shard_index=1, shard_count=2, row_tile=4)
+    want = oracle.render(37, 45, 33, ref_camera, objs, seeding=0, math=1, arith=0).pixels
+    rows = tor.shard_rows(37, 4, 1, 2)
+    _assert_parity(cv.pixels[rows], want[rows])
+
+
+def test_high_spp_sums_stay_exact(tor, oracle, ref_scene, ref_camera):
+    """BASELINE config C4 uses 4096 spp: the 2^-36-quantised per-pixel sums must stay exact (sum < 2^17)."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = _render(tor, scene, cam, 6, 10, 4096, seeding=tor.SEED_SAMPLE)
+    want = oracle.render(6, 10, 4096, ref_camera, objs, seeding=1, math=1, arith=0, accum=1).pixels
+    _assert_parity(cv.pixels, want)
+
+
 def test_row_sharding_is_exact(tor):
     """Any row partition gives the same pixels: shards written in place."""
     scene, cam = tor.random_scene(0xFACADE), tor.camera()

@@ -85,6 +85,7 @@ struct TorContext {
   bool scene_ready = false;
   // work
   DeviceBuffer counters;  // [0] work counter, [1..4] stats
+  DeviceBuffer tile_cost, tile_order;  // SEED_PIXEL cost-ordered schedule
   DeviceBuffer wave_log;  // debug: 4 x u64 per wave (only with stats enabled)
   DeviceBuffer cam_ring;  // 64 x TorCamera: one slot per in-flight launch (async-safe)
   DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
@@ -104,6 +105,7 @@ struct TorContext {
   //           holds one must get good service
   // Overridable for experiments: TOR_WAVES_PER_SIMD (4|5), TOR_BLOCKS_PER_CU.
   int max_blocks_per_cu[2] = {2, 3};  // [seeding]
+  int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
   int waves_per_simd = 4;  // register budget variant of the integrator (4: 128 VGPR, 5: 96 VGPR)
 };
 
@@ -167,6 +169,7 @@ int tor_context_create(int32_t device, TorContext** out) {
   }
   ctx->num_cus = prop.multiProcessorCount;
   if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_per_simd = (std::atoi(w) >= 5) ? 5 : 4;
+  if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU")) ctx->max_blocks_per_cu[0] = ctx->max_blocks_per_cu[1] = std::atoi(b);
   e = ctx->counters.ensure(8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kEventRing * sizeof(TorCamera));
@@ -193,6 +196,8 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->counters.release();
   ctx->cam_ring.release();
   ctx->wave_log.release();
+  ctx->tile_cost.release();
+  ctx->tile_order.release();
   ctx->scratch.release();
   for (int i = 0; i < TorContext::kEventRing; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
@@ -417,10 +422,14 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.out = d_pixels;
 
   long long waves;
+  p.n_pixels = (unsigned)npix;
+  p.order = nullptr;
+  p.tile_cost = nullptr;
+  const long long n_tiles = (npix + tor::kTilePixelsHost - 1) / tor::kTilePixelsHost;
   if (o.seeding == TOR_SEED_PIXEL) {
-    p.total_work = (unsigned long long)npix;
-    p.chunk = 64;
-    waves = (npix + 63) / 64;
+    p.total_work = (unsigned long long)n_tiles * tor::kTilePixelsHost;  // tiles of 64 pixels
+    p.chunk = tor::kTilePixelsHost;
+    waves = n_tiles;
   } else {
     p.total_work = (unsigned long long)npix * (unsigned long long)spp;
     long long c = (long long)(p.total_work / (unsigned long long)(resident_waves * 16));
@@ -447,6 +456,30 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
   HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, cam, sizeof(TorCamera), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+  if (o.seeding == TOR_SEED_PIXEL && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && n_tiles > 1) {
+    // Cost-ordered schedule: a 2-spp probe (per-sample streams; it only counts closest-hit queries
+    // per tile, it never touches the canvas) + a counting sort; ~2/spp of extra work.
+    HIP_TRY(ctx->tile_cost.ensure((size_t)n_tiles * 4));
+    HIP_TRY(ctx->tile_order.ensure((size_t)n_tiles * 4));
+    HIP_TRY(hipMemsetAsync(ctx->tile_cost.ptr, 0, (size_t)n_tiles * 4, stream));
+    tor::KParams pp = p;
+    pp.spp = 2;
+    pp.total_work = (unsigned long long)npix * 2ull;
+    pp.chunk = 256;
+    pp.work_counter = (unsigned long long*)ctx->counters.ptr + 5;
+    pp.stats = nullptr;
+    pp.wave_log = nullptr;
+    pp.out = nullptr;
+    pp.tile_cost = (unsigned*)ctx->tile_cost.ptr;
+    long long pw = (long long)((pp.total_work + 63) / 64);
+    const long long pres = (long long)ctx->num_cus * 3 * (tor::kThreads / 64);
+    if (pw > pres) pw = pres;
+    const int pblocks = (int)((pw + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
+    pp.n_waves = (unsigned)(pblocks * (tor::kThreads / 64));
+    HIP_TRY(tor::launch_probe(pp, pblocks, stream));
+    HIP_TRY(tor::launch_tile_order((const unsigned*)ctx->tile_cost.ptr, (unsigned*)ctx->tile_order.ptr, (int)n_tiles, stream));
+    p.order = (const unsigned*)ctx->tile_order.ptr;
+  }
   HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, ctx->waves_per_simd, blocks, stream));
   HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
   ctx->launches += 1;

@@ -88,6 +88,7 @@ __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, doub
 
 constexpr int kQCap = 16;   // candidate-queue entries per lane (LDS, u32): (block << 8) | 8-bit mask
 constexpr int kBlock = 8;   // objects per queue entry; hot arrays are padded to this (= kPad)
+constexpr int kTilePixels = 64;  // SEED_PIXEL work unit: one wave-load of consecutive pixels
 constexpr int kAccSlots = 16;  // per-wave LDS pixel-accumulator cache (TOR_SEED_SAMPLE)
 static_assert(kBlock == kPad, "hot-record padding must equal the candidate block size");
 
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const cdptr segs = as_const(p.segs);
   const double w_div = (double)(p.ncols - 1);  // render.nim:64 divides by float64(ncols-1)
   const double h_div = (double)(p.nrows - 1);
+  constexpr bool kProbe = (SEEDING == 2);  // cost probe for the SEED_PIXEL tile schedule
 
   if (SEEDING == 1) {
     if (lane < kAccSlots) {
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   int depth = 0;
   int row = 0, col = 0, s = 0;
   int pix = -1;             // index into p.out (local pixel)
+  int path_q = 0;           // probe: closest-hit queries of the current path
   V3 acc = v3(0, 0, 0);     // SEED_PIXEL: the pixel's sum, in sample order
 
   // ---- wave-uniform work range: [w_next, w_end) of the global index space; (cur_pl, cur_s)
@@ -188,8 +191,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           w_next = base;
           w_end = (base + grab < p.total_work) ? base + grab : p.total_work;
           if (SEEDING == 0) {
-            cur_pl = (unsigned)base;
+            // work index space = tiles of kTilePixels pixels, optionally in cost order (LPT): the
+            // k-th fetch renders tile order[k]
+            unsigned tile = (unsigned)(base / kTilePixels);
+            if (p.order != nullptr) tile = p.order[tile];
+            cur_pl = tile * kTilePixels;
             cur_s = 0;
+            const unsigned left_px = p.n_pixels - cur_pl;
+            w_end = base + ((left_px < (unsigned)kTilePixels) ? left_px : (unsigned)kTilePixels);
           } else {  // one 64-bit division per chunk, wave-uniform
             unsigned long long pl0 = base / (unsigned)p.spp;
             cur_pl = (unsigned)pl0;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             pl = cur_pl + prefix;
             s = 0;
             acc = v3(0, 0, 0);
-          } else {
+          } else {  // sample and probe
             const unsigned t = cur_s + prefix;
             const unsigned dp = t / (unsigned)p.spp;
             pl = cur_pl + dp;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       }
     }
     if (!active && have_item) {
-      if (SEEDING == 1) seed3(rng, (uint64_t)row, (uint64_t)col, (uint64_t)s);
+      if (SEEDING != 0) seed3(rng, (uint64_t)row, (uint64_t)col, (uint64_t)s);
       have_item = false;  // the pending sample is consumed by starting its path
       // render.nim:64-66
       const double u = ((double)col + uniform01(rng)) / w_div;
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     }
     st_iters += 1;
     st_queries += (unsigned long long)__builtin_popcountll(active_mask);
+    if (kProbe && active) path_q += 1;
     bool ended = false;
     V3 radiance = v3(0.0, 0.0, 0.0);
     if (active) {
@@ -480,6 +490,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       if (ended) {
         active = false;
         st_samples += 1;
+        if (kProbe) {
+          atomicAdd(p.tile_cost + ((unsigned)pix / kTilePixels), (unsigned)path_q);
+          path_q = 0;
+        }
         if (SEEDING == 0) {
           acc = acc + radiance;  // render.nim:67
           s += 1;
@@ -554,6 +568,36 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   }
 }
 
+// Tile schedule for SEED_PIXEL: counting sort of the tiles by probed cost, most expensive first
+// (longest-processing-time-first: a pixel is a sequential chain of spp samples, so the expensive
+// chains must start at t = 0).  One workgroup; the order of equal-cost tiles is irrelevant (the
+// schedule never changes a pixel's value).
+constexpr int kCostBins = 8192;
+__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* cost, unsigned* order, int n_tiles) {
+  __shared__ unsigned hist[kCostBins];
+  __shared__ unsigned offs[kCostBins];
+  for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+    unsigned c = cost[i];
+    atomicAdd(&hist[c < (unsigned)kCostBins ? c : (unsigned)kCostBins - 1], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int b = kCostBins - 1; b >= 0; --b) {  // descending cost
+      offs[b] = run;
+      run += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+    unsigned c = cost[i];
+    unsigned b = c < (unsigned)kCostBins ? c : (unsigned)kCostBins - 1;
+    order[atomicAdd(&offs[b], 1u)] = (unsigned)i;
+  }
+}
+
 // canvas.nim:47-54
 __global__ __launch_bounds__(256) void finalize_kernel(double* pixels, long long n_values, double scale,
                                                         double gamma) {
@@ -589,6 +633,17 @@ static hipError_t launch_integrate_w(const KParams& p, int seeding, int arith, i
   else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1, W>), grid, block, smem, stream, p);
   else if (seeding == 1 && arith == 0) hipLaunchKernelGGL((integrate_kernel<1, 0, W>), grid, block, smem, stream, p);
   else hipLaunchKernelGGL((integrate_kernel<1, 1, W>), grid, block, smem, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
+  hipLaunchKernelGGL((integrate_kernel<2, 0, 4>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream) {
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles);
   return hipGetLastError();
 }
 

@@ -35,6 +35,9 @@ struct KParams {
   int shard_index, shard_count, row_tile;
   unsigned chunk;   // SEED_SAMPLE: largest chunk of the guided schedule
   unsigned n_waves; // waves launched
+  unsigned n_pixels;  // local pixels (rows of this shard x ncols)
+  const unsigned* order;  // SEED_PIXEL: nullable tile order (cost-descending), n_tiles entries
+  unsigned* tile_cost;    // probe launch: per-tile closest-hit query count
   unsigned long long total_work;
   unsigned long long* work_counter;
   double* out;
@@ -46,6 +49,9 @@ struct KParams {
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream);
 int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd);
+hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
+hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream);
+constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
 hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
