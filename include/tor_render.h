@@ -225,6 +225,19 @@ TOR_API int tor_camera_init(TorCamera* out, const TorVec3* look_from, const TorV
  * Returns the number of objects written, or a negative status if cap is too small. */
 TOR_API int64_t tor_random_scene(uint64_t seed, TorHittableVariant* out, int64_t cap);
 
+/* Animated scene (BASELINE config 5) -- trace_of_radiance/scenes_animated.nim.
+ * tor_animation_create = random_moving_spheres (:90-154) with rng.seed(seed);
+ * tor_animation_next   = one turn of `iterator scenes(anim, skip)` (:176-225): returns 1 and fills
+ *                        (cam, objects[0 .. *n_out)) when a frame is due, 0 once anim.t >= t_max.
+ * Frames are independent given (cam, objects): a frame-parallel host gives frame f to GPU f mod N. */
+typedef struct TorAnimation TorAnimation;
+TOR_API int tor_animation_create(uint64_t seed, int32_t height, int32_t width, float dt, float t_min,
+                                 float t_max, TorAnimation** out);
+TOR_API void tor_animation_destroy(TorAnimation* anim);
+TOR_API int64_t tor_animation_object_count(const TorAnimation* anim);
+TOR_API int tor_animation_next(TorAnimation* anim, int32_t skip, TorCamera* cam, TorHittableVariant* objects,
+                               int64_t cap, int64_t* n_out, float* t_out);
+
 /* exportToPPM's quantiser on a host canvas -- io/ppm.nim:14-27.  out: nrows*ncols*3 bytes,
  * first row = top scanline. */
 TOR_API int tor_canvas_to_rgb8(const TorCanvas* canvas, uint8_t* out);

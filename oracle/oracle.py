@@ -96,6 +96,13 @@ def lib(variant: str | None = None):
     L.oracle_quantize36.restype = C.c_double
     L.oracle_quantize_ppm.argtypes = [dp, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
     L.oracle_num_threads.restype = C.c_int
+    L.oracle_animation_create.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float]
+    L.oracle_animation_create.restype = C.c_void_p
+    L.oracle_animation_destroy.argtypes = [C.c_void_p]
+    L.oracle_animation_object_count.argtypes = [C.c_void_p]
+    L.oracle_animation_object_count.restype = C.c_int64
+    L.oracle_animation_next.argtypes = [C.c_void_p, C.c_int32, dp, dp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+    L.oracle_animation_next.restype = C.c_int
     if variant is None:
         _lib = L
     return L
@@ -169,3 +176,25 @@ def quantize_ppm(pixels: np.ndarray) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
+
+
+def animation_scenes(height, width, dt=0.005, t_min=0.0, t_max=2.0, skip=6, seed=0xFACADE, max_frames=None):
+    """scenes_animated.nim:90-225 -> yields (cam[24], objs[n,16], t) per frame."""
+    L = lib()
+    h = L.oracle_animation_create(seed, height, width, dt, t_min, t_max)
+    try:
+        n_obj = int(L.oracle_animation_object_count(h))
+        k = 0
+        while max_frames is None or k < max_frames:
+            cam = np.zeros(24, dtype=np.float64)
+            objs = np.zeros((n_obj, 16), dtype=np.float64)
+            n = C.c_int64(0)
+            t = C.c_float(0)
+            rc = L.oracle_animation_next(h, skip, _dp(cam), _dp(objs), n_obj, C.byref(n), C.byref(t))
+            if rc == 0:
+                return
+            assert rc == 1 and n.value == n_obj
+            yield cam, objs, float(t.value)
+            k += 1
+    finally:
+        L.oracle_animation_destroy(h)

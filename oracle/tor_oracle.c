@@ -786,3 +786,111 @@ EXPORT int oracle_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------- */
+/* Animated scene (scenes_animated.nim) -- oracle restatement                  */
+/* ------------------------------------------------------------------------- */
+/* PARITY UNPINNED for this generator: the reference holds no rendered frame of it, and HEAD
+ * does not compile `rng.random(float32)` (scenes_animated.nim:122,136,148; no such overload in
+ * sampling.nim:18-25).  Read here as float32(uniform(float64)) with float32 arithmetic. */
+
+typedef struct {
+  double velocity, pos_y, coef_restitution, x, z, radius; /* scenes_animated.nim:37-49 */
+  double mat, ax, ay, az, fuzz, ri;
+} OBall;
+
+typedef struct {
+  int32_t nrows, ncols;
+  float dt, t_min, t_max, t;
+  double look_from_angle;
+  int64_t n;
+  int skipped;
+  OBall balls[1700];
+} OAnim;
+
+static double o_velocity_draw(Rng* g) { /* :122 `Velocity(10.0 + (4 * rng.random(float32) - 2.0))` */
+  float u = (float)uniform01(g, NULL);
+  float v = 10.0f + (4.0f * u - 2.0f);
+  return (double)v;
+}
+
+EXPORT void* oracle_animation_create(uint64_t seed, int32_t height, int32_t width, float dt, float t_min, float t_max) {
+  OAnim* a = (OAnim*)calloc(1, sizeof(OAnim));
+  if (!a) return NULL;
+  a->nrows = height; a->ncols = width; a->dt = dt; a->t_min = t_min; a->t_max = t_max;
+  a->t = 0.0f;
+  a->look_from_angle = 2 * 3.141592653589793; /* :104 */
+  Rng g; rng_seed1(&g, seed);
+  for (int ia = -20; ia < 20; ++ia)
+    for (int ib = -20; ib < 20; ++ib) {
+      double cx = (double)ia + 0.9 * uniform01(&g, NULL);
+      double cz = (double)ib + 0.9 * uniform01(&g, NULL);
+      V3 center = v3(cx, 0.2, cz);
+      if (sqrt(vlen2(vsub(center, v3(4, 0.2, 0)))) > 0.9) {
+        double choose = uniform01(&g, NULL);
+        OBall* b = &a->balls[a->n++];
+        if (choose < 0.65) { /* :117-129 */
+          double a0 = uniform01(&g, NULL), a1 = uniform01(&g, NULL), a2 = uniform01(&g, NULL);
+          double b0 = uniform01(&g, NULL), b1 = uniform01(&g, NULL), b2 = uniform01(&g, NULL);
+          b->coef_restitution = 0.6; b->velocity = o_velocity_draw(&g);
+          b->mat = MAT_LAMBERTIAN; b->ax = a0 * b0; b->ay = a1 * b1; b->az = a2 * b2;
+        } else if (choose < 0.95) { /* :130-143 */
+          double r0 = uniform_range(&g, 0.5, 1, NULL), r1 = uniform_range(&g, 0.5, 1, NULL), r2 = uniform_range(&g, 0.5, 1, NULL);
+          double fuzz = uniform_max(&g, 0.5, NULL);
+          b->coef_restitution = 0.5; b->velocity = o_velocity_draw(&g);
+          b->mat = MAT_METAL; b->ax = r0; b->ay = r1; b->az = r2; b->fuzz = (fuzz <= 1.0) ? fuzz : 1.0;
+        } else { /* :145-154 */
+          b->coef_restitution = 0.5; b->velocity = o_velocity_draw(&g);
+          b->mat = MAT_DIELECTRIC; b->ri = 1.5;
+        }
+        b->x = center.x; b->pos_y = center.y; b->z = center.z; b->radius = 0.2;
+      }
+    }
+  return a;
+}
+
+EXPORT void oracle_animation_destroy(void* h) { free(h); }
+EXPORT int64_t oracle_animation_object_count(void* h) { return ((OAnim*)h)->n + 4; }
+
+static void o_anim_step(OAnim* a) { /* :156-174 */
+  a->look_from_angle -= 2.0 * 3.141592653589793 / 1200.0;
+  a->t += a->dt;
+  double dt64 = (double)a->dt;
+  for (int64_t i = 0; i < a->n; ++i) {
+    OBall* b = &a->balls[i];
+    if (b->velocity < 0.0 && b->pos_y < 0.2) b->velocity = -b->coef_restitution * b->velocity;
+    else b->velocity -= 9.80665 * dt64;
+    b->pos_y += b->velocity * dt64;
+  }
+}
+
+static void o_static(Obj* o, double x, double y, double z, double r) { obj_sphere(o, v3(x, y, z), r); }
+
+/* iterator scenes -- :176-225.  Returns 1 (frame produced), 0 (finished). */
+EXPORT int oracle_animation_next(void* h, int32_t skip, double cam24[24], double* objs16, int64_t cap, int64_t* n_out, float* t_out) {
+  OAnim* a = (OAnim*)h;
+  if (!a->skipped) { while (a->t < a->t_min) o_anim_step(a); a->skipped = 1; }
+  if (!(a->t < a->t_max)) return 0;
+  if (cap < a->n + 4) return -1;
+  double aspect = (double)a->ncols / (double)a->nrows;
+  double r = sqrt(200.0);
+  double lf[3] = { r * cos(a->look_from_angle), 2.0, r * sin(a->look_from_angle) };
+  double la[3] = { 4, 1, 0 }, up[3] = { 0, 1, 0 };
+  oracle_camera(lf, la, up, 20.0, aspect, 0.1, 10.0, 0.0, 0.0, cam24);
+  Obj* objs = (Obj*)objs16;
+  int64_t k = 0;
+  o_static(&objs[k], 0, -1000, 0, 1000); mat_lambertian(&objs[k], v3(0.5, 0.5, 0.5)); k++;
+  for (int64_t i = 0; i < a->n; ++i) {
+    OBall* b = &a->balls[i];
+    o_static(&objs[k], b->x, b->pos_y, b->z, b->radius);
+    objs[k].mat = b->mat; objs[k].ax = b->ax; objs[k].ay = b->ay; objs[k].az = b->az; objs[k].fuzz = b->fuzz; objs[k].ri = b->ri;
+    k++;
+  }
+  o_static(&objs[k], 0, 1, 0, 1.0); mat_dielectric(&objs[k], 1.5); k++;
+  o_static(&objs[k], -4, 1, 0, 1.0); mat_lambertian(&objs[k], v3(0.4, 0.2, 0.1)); k++;
+  o_static(&objs[k], 4, 1, 0, 1.0); mat_metal(&objs[k], v3(0.7, 0.6, 0.5), 0.0); k++;
+  *n_out = k;
+  if (t_out) *t_out = a->t;
+  for (int32_t i = 0; i < skip; ++i) o_anim_step(a);
+  return 1;
+}

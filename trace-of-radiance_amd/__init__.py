@@ -120,7 +120,8 @@ EXPORTED_SYMBOLS = [
     "tor_render", "tor_render_opt", "tor_last_error", "tor_context_create", "tor_context_destroy",
     "tor_scene_upload", "tor_shard_rows", "tor_render_device", "tor_quantize_rgb8_device",
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
-    "tor_random_scene", "tor_canvas_to_rgb8", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
+    "tor_animation_object_count", "tor_animation_next", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -179,6 +180,14 @@ def lib():
     L.tor_random_scene.argtypes = [C.c_uint64, C.POINTER(HittableVariant), C.c_int64]
     L.tor_random_scene.restype = C.c_int64
     L.tor_canvas_to_rgb8.argtypes = [C.POINTER(CanvasStruct), C.POINTER(C.c_uint8)]
+    L.tor_animation_create.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                       C.POINTER(C.c_void_p)]
+    L.tor_animation_destroy.argtypes = [C.c_void_p]
+    L.tor_animation_destroy.restype = None
+    L.tor_animation_object_count.argtypes = [C.c_void_p]
+    L.tor_animation_object_count.restype = C.c_int64
+    L.tor_animation_next.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Camera), C.POINTER(HittableVariant), C.c_int64,
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_float)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -293,6 +302,48 @@ def random_scene(seed: int = 0xFACADE) -> Scene:
     if n < 0:
         raise TorError(int(n), "tor_random_scene failed")
     return Scene(arr, int(n))
+
+
+class Animation:
+    """random_moving_spheres + `iterator scenes` -- trace_of_radiance/scenes_animated.nim:90-225.
+
+    ``for cam, scene, t in Animation(h, w, dt, t_min, t_max).scenes(skip=6): render(canvas, cam, scene.list(), depth)``
+    mirrors trace_of_radiance_animation.nim:84-97."""
+
+    def __init__(self, height: int, width: int, dt: float = 0.005, t_min: float = 0.0, t_max: float = 2.0,
+                 seed: int = 0xFACADE):
+        self._h = C.c_void_p()
+        _check(lib().tor_animation_create(seed, height, width, dt, t_min, t_max, C.byref(self._h)))
+        self.n_objects = int(lib().tor_animation_object_count(self._h))
+
+    def scenes(self, skip: int = 6):
+        while True:
+            cam = Camera()
+            arr = (HittableVariant * self.n_objects)()
+            n = C.c_int64(0)
+            t = C.c_float(0)
+            rc = lib().tor_animation_next(self._h, skip, C.byref(cam), arr, self.n_objects, C.byref(n), C.byref(t))
+            if rc == 0:
+                return
+            if rc < 0:
+                raise TorError(rc, "tor_animation_next failed")
+            yield cam, Scene(arr, int(n.value)), float(t.value)
+
+    def close(self):
+        if self._h:
+            lib().tor_animation_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def frames_of_rank(n_frames: int, rank: int, world: int):
+    """Frame-parallel split of an animation: frame f is rendered by GPU f mod world."""
+    return list(range(rank, n_frames, max(world, 1)))
 
 
 class Canvas:
