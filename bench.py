@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--row-tile", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2: random_scene frame (default, the metric's config); c5: BASELINE configs[4], the animated "
+                         "bouncing-spheres scene, 256 spp per frame, frames dealt round-robin to the GPUs (no collective)")
     ap.add_argument("--stats", action="store_true", help="also collect the kernel's workload counters (untimed extra step)")
     return ap.parse_args()
 
@@ -97,6 +100,64 @@ def cpu_baseline(width, height, spp, depth, target_seconds):
     }
 
 
+def bench_animation(args, tor, torch, dist, world, rank, local_rank):
+    """BASELINE configs[4]: scenes_animated bouncing spheres, frame-parallel (frame f -> GPU f mod N,
+    SURVEY 8e): a step = one frame per GPU: scene upload (1601 objects) + integrator.  No collective."""
+    H, W = args.height, args.width
+    spp = args.spp if args.spp != 100 else 256
+    seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
+    arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
+    n_steps = args.warmup + args.steps
+    anim = tor.Animation(H, W, 0.005, 0.0, 7.2)   # 240 frames at skip 6
+    frames = []
+    for f, (cam, scene, t) in enumerate(anim.scenes(6)):
+        if f >= n_steps * max(world, 1):
+            break
+        if f % max(world, 1) == (rank if world > 1 else 0):
+            frames.append((cam, scene))
+    ctx = tor.Context(local_rank if world > 1 else 0)
+    opt = tor.make_options(seeding=seeding, arith=arith)
+    buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        cam, scene = frames[i]
+        ctx.upload(scene.list())
+        ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt, buf.data_ptr(), stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_ms, k_n = ctx.kernel_ms_mean(args.steps)
+    if rank == 0:
+        total = H * W * spp * args.steps * max(world, 1)
+        print(json.dumps({
+            "metric": "Msamples/s (pixels x spp / s) on the animated bouncing-spheres scene", "value": round(total / elapsed / 1e6, 2),
+            "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: scenes_animated (1601 static spheres per frame), {W}x{H}, {spp} spp, "
+                                   f"depth {args.depth}, one frame per GPU per step", "seeding": args.seeding, "arith": args.arith,
+                       "parallelism": f"frame f -> GPU f mod {max(world, 1)}, no collective"},
+            "kernel_ms": round(k_ms, 3), "frames_per_s": round(args.steps * max(world, 1) / elapsed, 3)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     import torch
@@ -115,6 +176,8 @@ def main():
     tor = importlib.import_module("trace-of-radiance_amd")
 
     H, W = args.height, args.width
+    if args.workload == "c5":
+        return bench_animation(args, tor, torch, dist, world, rank, local_rank)
     spp = args.spp * max(world, 1)  # weak scaling: per-GPU samples fixed
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
     arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
