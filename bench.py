@@ -60,6 +60,17 @@ def parse_args():
     return ap.parse_args()
 
 
+def measured_traffic(W, H, spp, seeding, arith):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json), for the configurations that were profiled; None otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        return t[f"{W}x{H}x{spp}:{seeding}:{arith}"]["bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(width, height, spp, depth, target_seconds):
     """The oracle in its reference-faithful mode (per-pixel streams, libm, no FMA), OpenMP over
     rows with schedule(dynamic,1) -- the analogue of Weave's parallelFor row (render.nim:55) --
@@ -237,7 +248,7 @@ def main():
             "frac_of_nofma_peak": round(tflops / PEAK_FP64_NOFMA_TFLOPS, 4),
             "nofma_peak": PEAK_FP64_NOFMA_TFLOPS,
             "flops_per_sample": FLOPS_PER_SAMPLE, "kernel_ms": round(k_ms, 3), "launches_averaged": k_n,
-            "traffic": None,
+            "traffic": measured_traffic(W, H, spp, args.seeding, args.arith) if world == 1 else None,
             "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 4), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 8),
                     "algorithmic_bytes_per_launch": hbm_bytes},

@@ -195,6 +195,29 @@ def test_invalid_arguments_fail_loudly(tor):
         tor.render(tor.new_canvas(4, 4, 1), cam, scene.list(), 50, tor.make_options(shard_index=3, shard_count=2))
 
 
+def test_full_size_rows_match_oracle(tor, oracle, ref_scene, ref_camera):
+    """BASELINE config C2 (1920x1080x100 spp) on the GPU; the oracle renders 5 of its rows (bottom, the
+    sphere field, the glass ball, horizon, sky) and those rows must match bit for bit."""
+    import torch
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    ctx = tor.Context()
+    ctx.upload(scene.list())
+    h, w, spp = 1080, 1920, 100
+    rows = [0, 377, 540, 731, 1079]
+    for seeding in (tor.SEED_SAMPLE, tor.SEED_PIXEL):
+        buf = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        ctx.render_device(cam, h, w, spp, 2.2, 50, tor.make_options(seeding=seeding), buf.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        for r in rows:
+            want = oracle.render(h, w, spp, ref_camera, objs, seeding=seeding, math=1, arith=0, accum=seeding,
+                                 rows=(r, r + 1)).pixels[r]
+            _assert_parity(got[r], want)
+    ctx.close()
+
+
 def test_full_size_properties(tor):
     """BASELINE config C2 geometry (1920x1080), size-independent properties: determinism,
     shard invariance of the device path, finite values in range, quantiser idempotence."""
