@@ -42,7 +42,6 @@ namespace tor {
 
 // scalar (constant address space) view of the read-only scene so the compiler emits s_load
 typedef const double __attribute__((address_space(4))) * cdptr;
-typedef const int32_t __attribute__((address_space(4))) * ciptr;
 
 __device__ __forceinline__ cdptr as_const(const double* p) { return (cdptr)(uintptr_t)p; }
 

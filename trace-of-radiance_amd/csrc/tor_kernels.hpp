@@ -11,7 +11,7 @@
 namespace tor {
 
 constexpr int kThreads = 256;  // 4 waves per workgroup
-constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of this (= kUnroll)
+constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of this (= kBlock, the candidate-mask width)
 
 // Device scene (built by tor_scene_upload from the AoS HittableVariant list):
 //   stat : static spheres, 4 float64 each   {cx, cy, cz, radius^2}
