@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seeding", choices=["sample", "pixel"], default="sample")
     ap.add_argument("--arith", choices=["strict", "fused"], default="strict")
+    ap.add_argument("--accel", choices=["none", "blocks"], default="none",
+                    help="none: the reference's brute-force closest hit (the metric's algorithm); blocks: exact block culling (SURVEY 8 f4)")
     ap.add_argument("--row-tile", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,7 +129,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
         if f % max(world, 1) == (rank if world > 1 else 0):
             frames.append((cam, scene))
     ctx = tor.Context(local_rank if world > 1 else 0)
-    opt = tor.make_options(seeding=seeding, arith=arith)
+    opt = tor.make_options(seeding=seeding, arith=arith, accel=tor.ACCEL_BLOCKS if args.accel == "blocks" else tor.ACCEL_NONE)
     buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -198,7 +200,8 @@ def main():
     ctx = tor.Context(local_rank if world > 1 else 0)
     ctx.upload(scene.list())
     opt = tor.make_options(seeding=seeding, arith=arith, shard_index=rank if world > 1 else 0,
-                           shard_count=max(world, 1), row_tile=args.row_tile)
+                           shard_count=max(world, 1), row_tile=args.row_tile,
+                           accel=tor.ACCEL_BLOCKS if args.accel == "blocks" else tor.ACCEL_NONE)
     tdist = importlib.import_module("trace-of-radiance_amd.distributed")
     plan = tdist.ShardPlan(H, args.row_tile, max(world, 1))
     frame = tdist.DistributedFrame(plan, W, rank if world > 1 else 0, torch.device("cuda"))
@@ -262,7 +265,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
                                    f"{spp} spp ({args.spp} per GPU), depth {args.depth}",
-                       "seeding": args.seeding, "arith": args.arith,
+                       "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
                        "parallelism": f"row tiles of {args.row_tile} dealt to {max(world, 1)} rank(s)" +
                                       (" + RCCL all_gather of the framebuffer" if world > 1 else "")},
             "roofline": roof,

@@ -113,6 +113,13 @@ enum {
   TOR_ARITH_FUSED = 1   /* same formulas with explicit fma(); throughput variant          */
 };
 
+/* Candidate culling.  Never changes a pixel: closest hit is order independent. */
+enum {
+  TOR_ACCEL_NONE = 0,   /* the reference's algorithm: every ray against every object (default)      */
+  TOR_ACCEL_BLOCKS = 1  /* objects in spatial blocks of 8 with conservative bounding spheres; a ray  */
+                        /* only expands the blocks whose bound it can touch                          */
+};
+
 typedef struct TorOptions {
   uint32_t struct_size; /* = sizeof(TorOptions) */
   int32_t seeding;      /* TOR_SEED_*  (default TOR_SEED_PIXEL)  */
@@ -122,7 +129,7 @@ typedef struct TorOptions {
    * tiles of row_tile rows; tile t is rendered by shard (t mod shard_count).  The shard's
    * rows are written compactly, in increasing row order.  shard_count <= 1: whole image. */
   int32_t shard_index, shard_count, row_tile;
-  int32_t reserved;
+  int32_t accel;        /* TOR_ACCEL_* (default TOR_ACCEL_NONE) */
 } TorOptions;
 
 /* Status codes (the reference's render() returns void and has no error path; this ABI

@@ -128,6 +128,55 @@ def test_high_spp_sums_stay_exact(tor, oracle, ref_scene, ref_camera):
     _assert_parity(cv.pixels, want)
 
 
+def test_block_culling_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
+    """TOR_ACCEL_BLOCKS: spatial blocks of 8 objects behind conservative bounding
+    spheres.  Closest hit is order independent (hittables_lists.nim:48-55), so the canvases must
+    be bit-identical to the brute-force path and to the oracle -- random_scene (395 moving + 90
+    static spheres), an animated frame (1601 static spheres), and a scene with several time
+    groups, general movers, overlapping, duplicate and negative-radius spheres."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    for seeding in (tor.SEED_PIXEL, tor.SEED_SAMPLE):
+        for arith in (0, 1):
+            base = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, arith=arith)
+            acc = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, arith=arith, accel=tor.ACCEL_BLOCKS)
+            assert np.array_equal(acc.pixels, base.pixels), (seeding, arith)
+        want = oracle.render(36, 64, 16, ref_camera, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels
+        acc = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, accel=tor.ACCEL_BLOCKS)
+        _assert_parity(acc.pixels, want)
+    # animated frame
+    cam2, scene2, _ = next(iter(tor.Animation(27, 48, 0.005, 0.3, 2.0).scenes(6)))
+    base = _render(tor, scene2, cam2, 27, 48, 8, seeding=tor.SEED_SAMPLE)
+    acc = _render(tor, scene2, cam2, 27, 48, 8, seeding=tor.SEED_SAMPLE, accel=tor.ACCEL_BLOCKS)
+    assert np.array_equal(acc.pixels, base.pixels)
+    # synthetic: 300 objects, 3 time groups (one general mover group), duplicates, hollow spheres, big ones
+    rng = np.random.default_rng(5)
+    recs = [[0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0]]
+    for i in range(300):
+        x, z = rng.uniform(-9, 9, 2)
+        kind = i % 4
+        mat = [0, 1, 2][i % 3]
+        r = 0.25 if i % 17 else -0.25
+        if kind == 0:
+            recs.append([0, x, .25, z, x, .25, z, 0, 1, r, mat, .6, .5, .4, 0.2, 1.5])
+        elif kind == 1:
+            recs.append([1, x, .25, z, x, .25 + rng.uniform(0, .6), z, 0.0, 1.0, r, mat, .3, .7, .4, 0.1, 1.5])
+        elif kind == 2:
+            recs.append([1, x, .25, z, x + rng.uniform(-.5, .5), .4, z + rng.uniform(-.5, .5), 0.25, 0.75, r, mat, .3, .3, .8, 0.0, 1.4])
+        else:
+            recs.append([1, x, .25, z, x, .25, z + .3, -1.0, 2.0, r, mat, .8, .3, .3, 0.4, 1.3])
+    recs.append(recs[5])                                                    # exact duplicate
+    recs.append([0, 0, 1, 0, 0, 1, 0, 0, 1, 1.0, 2, 0, 0, 0, 0, 1.5])       # big glass sphere
+    recs.append([1, 3, .3, 3, 3, .9, 3, 0.5, 0.5, 0.3, 0, .1, .9, .1, 0, 0])  # time0 == time1: never hit
+    scene3, recs3 = _custom_scene(tor, oracle, recs)
+    for seeding in (0, 1):
+        base = _render(tor, scene3, cam, 30, 52, 12, seeding=seeding)
+        acc = _render(tor, scene3, cam, 30, 52, 12, seeding=seeding, accel=tor.ACCEL_BLOCKS)
+        assert np.array_equal(acc.pixels, base.pixels), seeding
+        want = oracle.render(30, 52, 12, ref_camera, recs3, seeding=seeding, math=1, arith=0, accum=seeding).pixels
+        _assert_parity(acc.pixels, want)
+
+
 def test_row_sharding_is_exact(tor):
     """Any row partition gives the same pixels: shards written in place."""
     scene, cam = tor.random_scene(0xFACADE), tor.camera()

@@ -29,6 +29,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 SEED_PIXEL, SEED_SAMPLE = 0, 1
 ARITH_STRICT, ARITH_FUSED = 0, 1
+ACCEL_NONE, ACCEL_BLOCKS = 0, 1
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SPHERE, MOVING_SPHERE = 0, 1
 
@@ -104,7 +105,7 @@ class CanvasStruct(C.Structure):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("seeding", C.c_int32), ("arith", C.c_int32),
                 ("device", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("row_tile", C.c_int32), ("reserved", C.c_int32)]
+                ("row_tile", C.c_int32), ("accel", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -365,8 +366,8 @@ def new_canvas(height, width, samples_per_pixel, gamma_correction=2.2) -> Canvas
 
 
 def make_options(seeding=SEED_PIXEL, arith=ARITH_STRICT, device=-1, shard_index=0, shard_count=1,
-                 row_tile=1) -> Options:
-    return Options(C.sizeof(Options), seeding, arith, device, shard_index, shard_count, row_tile, 0)
+                 row_tile=1, accel=0) -> Options:
+    return Options(C.sizeof(Options), seeding, arith, device, shard_index, shard_count, row_tile, accel)
 
 
 def render(canvas: Canvas, cam: Camera, world: HittableList, max_depth: int, options: Options | None = None):

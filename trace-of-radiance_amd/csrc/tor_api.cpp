@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "tor_kernels.hpp"
+#include "tor_scene.hpp"
 
 // ---- layout guards: the structs must match what Nim's C backend emits --------
 static_assert(sizeof(TorVec3) == 24, "Vec3 is 3 x float64 (vec3s.nim:12-14)");
@@ -80,6 +81,10 @@ struct TorContext {
   int num_cus = 0;
   // scene
   DeviceBuffer stat, mov, movy, segs, cold;
+  // TOR_ACCEL_BLOCKS layout: always-list + spatial blocks; bounds travel per launch (ring)
+  tor::HostAccel accel;
+  DeviceBuffer a_stat, a_mov, a_movy, a_segs, a_cold, bnd_ring;
+  size_t bnd_slot_bytes = 0;
   int n_segs = 0;
   int64_t n_objects = 0;
   bool scene_ready = false;
@@ -126,6 +131,7 @@ bool valid_options(const TorOptions* opt, TorOptions& o) {
   }
   if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return false;
   if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return false;
+  if (o.accel != TOR_ACCEL_NONE && o.accel != TOR_ACCEL_BLOCKS) return false;
   if (o.shard_count < 1) o.shard_count = 1;
   if (o.row_tile < 1) o.row_tile = 1;
   if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
@@ -193,6 +199,8 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->movy.release();
   ctx->segs.release();
   ctx->cold.release();
+  ctx->a_stat.release(); ctx->a_mov.release(); ctx->a_movy.release(); ctx->a_segs.release();
+  ctx->a_cold.release(); ctx->bnd_ring.release();
   ctx->counters.release();
   ctx->cam_ring.release();
   ctx->wave_log.release();
@@ -223,136 +231,34 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
   if (world.len > (int64_t)1 << 24) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: too many objects");
   HIP_TRY(hipSetDevice(ctx->device));
   const int64_t n = world.len;
-  std::vector<int64_t> statics;
-  std::vector<std::pair<std::pair<uint64_t, uint64_t>, std::vector<int64_t>>> groups;
-  for (int64_t i = 0; i < n; ++i) {
-    const TorHittableVariant& h = world.objects[i];
-    if (h.kind == TOR_SPHERE) {
-      statics.push_back(i);
-    } else if (h.kind == TOR_MOVING_SPHERE) {
-      uint64_t k0, k1;
-      std::memcpy(&k0, &h.u.moving_sphere.time0, 8);
-      std::memcpy(&k1, &h.u.moving_sphere.time1, 8);
-      bool found = false;
-      for (auto& g : groups)
-        if (g.first.first == k0 && g.first.second == k1) {
-          g.second.push_back(i);
-          found = true;
-          break;
-        }
-      if (!found) groups.push_back({{k0, k1}, {i}});
-    } else {
-      return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown HittableVariant kind");
-    }
-  }
-  auto padded = [](size_t c) { return (c + tor::kPad - 1) / tor::kPad * tor::kPad; };
-  const size_t n_stat_p = padded(statics.size());
-  // a group moves "along y only" when every member has center1.x == center0.x and
-  // center1.z == center0.z: then c0 + f*(c1-c0) leaves x and z untouched, exactly
-  std::vector<char> yonly(groups.size(), 0);
-  size_t n_mov_p = 0, n_movy_p = 0;
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    bool y = true;
-    for (int64_t idx : groups[gi].second) {
-      const TorMovingSphere& s = world.objects[idx].u.moving_sphere;
-      if (!(s.center1.x - s.center0.x == 0.0 && s.center1.z - s.center0.z == 0.0)) { y = false; break; }
-    }
-    yonly[gi] = y ? 1 : 0;
-    (y ? n_movy_p : n_mov_p) += padded(groups[gi].second.size());
-  }
-  const size_t n_sorted = n_stat_p + n_mov_p + n_movy_p;
-  std::vector<double> stat(4 * n_stat_p + 8, 0.0), mov(8 * n_mov_p + 8, 0.0), movy(6 * n_movy_p + 8, 0.0),
-      cold(16 * n_sorted + 16, 0.0);
-  std::vector<double> segs;
-  // padding record: centre 0, radius^2 = -1  => discriminant <= -|d|^2 < 0, never a candidate
-  for (size_t k = 0; k < n_stat_p; ++k) stat[4 * k + 3] = -1.0;
-  for (size_t k = 0; k < n_mov_p; ++k) mov[8 * k + 3] = -1.0;
-  for (size_t k = 0; k < n_movy_p; ++k) movy[6 * k + 3] = -1.0;
-
-  auto fill_material = [&](double* c, const TorMaterial& m, int moving) -> bool {
-    int64_t flags = (moving ? 1 : 0) | ((int64_t)m.kind << 8);
-    c[13] = i64_as_double(flags);
-    switch (m.kind) {
-      case TOR_LAMBERTIAN:
-        c[9] = m.u.lambertian.albedo.x; c[10] = m.u.lambertian.albedo.y; c[11] = m.u.lambertian.albedo.z;
-        return true;
-      case TOR_METAL:
-        c[9] = m.u.metal.albedo.x; c[10] = m.u.metal.albedo.y; c[11] = m.u.metal.albedo.z;
-        c[12] = m.u.metal.fuzz;
-        return true;
-      case TOR_DIELECTRIC:
-        c[12] = m.u.dielectric.refraction_index;
-        return true;
-      default:
-        return false;
-    }
+  std::vector<int64_t> ids((size_t)n);
+  for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = i;
+  tor::HostLayout lay;
+  std::string err;
+  if (!tor::build_layout(world.objects, ids, lay, err)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: " + err);
+  ctx->n_segs = (int)(n == 0 ? 0 : lay.n_segs);
+  auto put = [](DeviceBuffer& b, const std::vector<double>& v) -> hipError_t {
+    hipError_t e = b.ensure(v.size() * 8);
+    if (e == hipSuccess) e = hipMemcpy(b.ptr, v.data(), v.size() * 8, hipMemcpyHostToDevice);
+    return e;
   };
-
-  size_t sorted = 0;
-  if (!statics.empty()) {
-    segs.insert(segs.end(), {0.0, 0.0, (double)n_stat_p, 0.0, 0.0, 0.0, 0.0, 0.0});
-    for (size_t k = 0; k < statics.size(); ++k) {
-      const TorSphere& s = world.objects[statics[k]].u.sphere;
-      stat[4 * k + 0] = s.center.x; stat[4 * k + 1] = s.center.y; stat[4 * k + 2] = s.center.z;
-      stat[4 * k + 3] = s.radius * s.radius;  // spheres.nim:32 `self.radius*self.radius`
-      double* c = &cold[16 * (sorted + k)];
-      c[0] = s.center.x; c[1] = s.center.y; c[2] = s.center.z;
-      c[6] = 1.0 / s.radius;  // vec3s.nim:93-94: `/ radius` is `* (1.0 / radius)`
-      c[14] = i64_as_double(statics[k]);
-      c[15] = s.radius * s.radius;
-      if (!fill_material(c, s.material, 0)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown Material kind");
-    }
-    sorted += n_stat_p;
+  HIP_TRY(put(ctx->stat, lay.stat));
+  HIP_TRY(put(ctx->mov, lay.mov));
+  HIP_TRY(put(ctx->movy, lay.movy));
+  HIP_TRY(put(ctx->segs, lay.segs));
+  HIP_TRY(put(ctx->cold, lay.cold));
+  // optional second level (TOR_ACCEL_BLOCKS): built now, bounds are computed per render call
+  tor::build_accel(world.objects, n, ctx->accel);
+  if (ctx->accel.available) {
+    HIP_TRY(put(ctx->a_stat, ctx->accel.always.stat));
+    HIP_TRY(put(ctx->a_mov, ctx->accel.always.mov));
+    HIP_TRY(put(ctx->a_movy, ctx->accel.always.movy));
+    HIP_TRY(put(ctx->a_segs, ctx->accel.always.segs));
+    HIP_TRY(put(ctx->a_cold, ctx->accel.cold));
+    const size_t n_bnd_p = (ctx->accel.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
+    ctx->bnd_slot_bytes = (8 * n_bnd_p + 16) * 8;
+    HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
   }
-  size_t mov_rec = 0, movy_rec = 0;
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    auto& g = groups[gi];
-    const size_t cnt_p = padded(g.second.size());
-    const TorMovingSphere& first = world.objects[g.second[0]].u.moving_sphere;
-    const double t0 = first.time0, dt = first.time1 - first.time0;  // moving_spheres.nim:42
-    const bool y = yonly[gi] != 0;
-    segs.insert(segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)cnt_p,
-                             (double)(sorted / tor::kPad), t0, dt, 0.0, 0.0});
-    for (size_t k = 0; k < g.second.size(); ++k) {
-      const TorMovingSphere& s = world.objects[g.second[k]].u.moving_sphere;
-      const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y,
-                   dcz = s.center1.z - s.center0.z;  // moving_spheres.nim:43
-      if (y) {
-        double* m = &movy[6 * (movy_rec + k)];
-        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
-        m[3] = s.radius * s.radius;
-        m[4] = dcy;
-      } else {
-        double* m = &mov[8 * (mov_rec + k)];
-        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
-        m[3] = s.radius * s.radius;
-        m[4] = dcx; m[5] = dcy; m[6] = dcz;
-      }
-      double* c = &cold[16 * (sorted + k)];
-      c[0] = s.center0.x; c[1] = s.center0.y; c[2] = s.center0.z;
-      c[3] = dcx; c[4] = dcy; c[5] = dcz;
-      c[6] = 1.0 / s.radius;
-      c[7] = t0; c[8] = dt;
-      c[14] = i64_as_double(g.second[k]);
-      c[15] = s.radius * s.radius;
-      if (!fill_material(c, s.material, 1)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown Material kind");
-    }
-    (y ? movy_rec : mov_rec) += cnt_p;
-    sorted += cnt_p;
-  }
-  if (segs.empty()) segs.assign(8, 0.0);  // empty world: one empty static segment
-  ctx->n_segs = (int)(n == 0 ? 0 : segs.size() / 8);
-
-  HIP_TRY(ctx->stat.ensure(stat.size() * 8));
-  HIP_TRY(ctx->mov.ensure(mov.size() * 8));
-  HIP_TRY(ctx->movy.ensure(movy.size() * 8));
-  HIP_TRY(ctx->segs.ensure(segs.size() * 8));
-  HIP_TRY(ctx->cold.ensure(cold.size() * 8));
-  HIP_TRY(hipMemcpy(ctx->stat.ptr, stat.data(), stat.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->mov.ptr, mov.data(), mov.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->movy.ptr, movy.data(), movy.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->segs.ptr, segs.data(), segs.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->cold.ptr, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
   ctx->n_objects = n;
   ctx->scene_ready = true;
   return TOR_OK;
@@ -415,6 +321,25 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.segs = (const double*)ctx->segs.ptr;
   p.cold = (const double*)ctx->cold.ptr;
   p.n_segs = ctx->n_segs;
+  p.bnd = nullptr;
+  p.spatial_base = 0;
+  std::vector<double> bnd_host;
+  bool use_accel = false;
+  if (o.accel == TOR_ACCEL_BLOCKS && ctx->accel.available) {
+    // rays carry the camera's shutter times, or 0 after a metal / dielectric bounce (rays.nim:19)
+    const double t_lo = std::fmin(0.0, std::fmin(cam->shutter_open, cam->shutter_close));
+    const double t_hi = std::fmax(0.0, std::fmax(cam->shutter_open, cam->shutter_close));
+    use_accel = tor::compute_block_bounds(ctx->accel, t_lo, t_hi, bnd_host);
+  }
+  if (use_accel) {
+    p.stat = (const double*)ctx->a_stat.ptr;
+    p.mov = (const double*)ctx->a_mov.ptr;
+    p.movy = (const double*)ctx->a_movy.ptr;
+    p.segs = (const double*)ctx->a_segs.ptr;
+    p.cold = (const double*)ctx->a_cold.ptr;
+    p.n_segs = ctx->accel.always.n_segs;
+    p.spatial_base = (int)ctx->accel.spatial_base;
+  }
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
   p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
   p.work_counter = (unsigned long long*)ctx->counters.ptr;
@@ -455,6 +380,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   // only after 64 further launches on this context)
   p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
   HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, cam, sizeof(TorCamera), hipMemcpyHostToDevice, stream));
+  if (use_accel) {
+    p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);
+    HIP_TRY(hipMemcpyAsync((void*)p.bnd, bnd_host.data(), bnd_host.size() * 8, hipMemcpyHostToDevice, stream));
+  }
   HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
   if (o.seeding == TOR_SEED_PIXEL && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && n_tiles > 1) {
     // Cost-ordered schedule: a 2-spp probe (per-sample streams; it only counts closest-hit queries

@@ -313,6 +313,32 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
             }
+          } else if (seg_kind == 3) {
+            // TOR_ACCEL_BLOCKS: the records are inflated axis-aligned boxes around spatial blocks of 8
+            // objects.  Slab test; a set bit means 'this lane has to look inside that block' and the
+            // entry is flagged with bit 31.  1/d may be +-inf (d = 0): (lo - o) * inf is +-inf, or
+            // NaN when lo == o, and v_min/v_max_f64 drop a NaN operand -- the axis then imposes no
+            // constraint, which is the conservative answer.
+            const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
+            cdptr rec = as_const(p.bnd) + 8 * (long)(seg_begin + i);
+            for (; i < seg_count; i += kBlock) {
+              unsigned m = 0;
+#pragma unroll
+              for (int j = 0; j < kBlock; ++j) {
+                const double tx0 = (rec[8 * j + 0] - ox) * ix, tx1 = (rec[8 * j + 3] - ox) * ix;
+                const double ty0 = (rec[8 * j + 1] - oy) * iy, ty1 = (rec[8 * j + 4] - oy) * iy;
+                const double tz0 = (rec[8 * j + 2] - oz) * iz, tz1 = (rec[8 * j + 5] - oz) * iz;
+                const double t_in = __builtin_fmax(__builtin_fmax(__builtin_fmin(tx0, tx1), __builtin_fmin(ty0, ty1)),
+                                                   __builtin_fmax(__builtin_fmin(tz0, tz1), 0.0));
+                const double t_out = __builtin_fmin(__builtin_fmin(__builtin_fmax(tx0, tx1), __builtin_fmax(ty0, ty1)),
+                                                    __builtin_fmax(tz0, tz1));
+                m = (m << 1) | ((t_in <= t_out) ? 1u : 0u);
+              }
+              rec += 8 * kBlock;
+              q[qn * 64] = 0x80000000u | ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+              qn += (m != 0) ? 1u : 0u;
+              if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+            }
           } else {
             // moving_spheres.nim:39-44: f = (time - time0) / (time1 - time0)
             const double t0 = segs[seg * 8 + 4], dt = segs[seg * 8 + 5];
@@ -365,20 +391,39 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         }
 
         // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
-        unsigned kq = 0, cur_mask = 0, cur_block = 0;
+        // Queue entries are 8-bit masks over a block of 8 consecutive cold slots (direct candidates)
+        // or, flagged with bit 31, over 8 block bounds: each set bit of those expands to the 8
+        // objects of that spatial block.  One object per lane per trip of the loop.
+        unsigned kq = 0, cur_mask = 0, cur_block = 0, cur_is_bound = 0;
+        unsigned exp_left = 0, exp_idx = 0;
         for (;;) {
-          if (cur_mask == 0 && kq < qn) {
+          if (exp_left == 0 && cur_mask == 0 && kq < qn) {
             const unsigned e = q[kq * 64];
             kq += 1;
-            cur_block = e >> 8;
+            cur_is_bound = e >> 31;
+            cur_block = (e >> 8) & 0x7fffffu;
             cur_mask = e & 0xffu;
           }
-          const bool has = cur_mask != 0;
+          const bool has = (exp_left != 0) || (cur_mask != 0);
           if (ballot64(has) == 0) break;
           if (has) {
-            const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> object j of the block
-            cur_mask &= ~(1u << b);
-            const unsigned idx = cur_block * kBlock + (unsigned)(7 - b);
+            unsigned idx;
+            if (exp_left != 0) {
+              idx = exp_idx;
+              exp_idx += 1;
+              exp_left -= 1;
+            } else {
+              const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> record j of the group
+              cur_mask &= ~(1u << b);
+              const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
+              if (cur_is_bound) {
+                idx = (unsigned)p.spatial_base + rec * kBlock;  // first object of spatial block `rec`
+                exp_idx = idx + 1;
+                exp_left = kBlock - 1;
+              } else {
+                idx = rec;
+              }
+            }
             st_cand += 1;
             const double* c = p.cold + (size_t)idx * 16;
             const double c0x = c[0], c0y = c[1], c0z = c[2];

@@ -19,7 +19,7 @@ constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of 
 //          with dc = center1 - center0, grouped by (time0, time1)
 //   movy : moving spheres of groups that move along y only, 6 float64 each
 //          {c0x, c0y, c0z, radius^2, dcy, 0}
-//   segs : 8 float64 per segment {kind (0 static, 1 moving along y only, 2 moving), first
+//   segs : 8 float64 per segment {kind (0 static, 1 moving along y only, 2 moving, 3 block bounds), first
 //          record, padded count, (first sorted index)/kPad, time0, time1 - time0, 0, 0}
 //   cold : 16 float64 per sorted slot {c0 xyz, dc xyz, 1/radius, time0, time1-time0,
 //          albedo xyz, fuzz|refraction_index, flags(bit0 moving, bits 8..15 material kind),
@@ -30,6 +30,8 @@ struct KParams {
   const double* movy;
   const double* segs;
   const double* cold;
+  const double* bnd;   // TOR_ACCEL_BLOCKS: 8 float64 per block {lo xyz, hi xyz, 0, 0} (segment kind 3), else null
+  int spatial_base;    // first cold slot of the spatial blocks: block b owns cold[spatial_base + 8b .. +8)
   int n_segs;
   int nrows, ncols, spp, max_depth;
   int shard_index, shard_count, row_tile;

@@ -1,0 +1,295 @@
+// tor_scene.cpp -- see tor_scene.hpp.
+#include "tor_scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <utility>
+
+#include "tor_kernels.hpp"
+
+namespace tor {
+
+namespace {
+
+inline double i64_as_double(int64_t v) {
+  double d;
+  std::memcpy(&d, &v, 8);
+  return d;
+}
+
+size_t padded(size_t c) { return (c + kPad - 1) / kPad * kPad; }
+
+// cold record (16 float64), see tor_kernels.hpp
+bool fill_material(double* c, const TorMaterial& m, int moving) {
+  int64_t flags = (moving ? 1 : 0) | ((int64_t)m.kind << 8);
+  c[13] = i64_as_double(flags);
+  switch (m.kind) {
+    case TOR_LAMBERTIAN:
+      c[9] = m.u.lambertian.albedo.x; c[10] = m.u.lambertian.albedo.y; c[11] = m.u.lambertian.albedo.z;
+      return true;
+    case TOR_METAL:
+      c[9] = m.u.metal.albedo.x; c[10] = m.u.metal.albedo.y; c[11] = m.u.metal.albedo.z;
+      c[12] = m.u.metal.fuzz;
+      return true;
+    case TOR_DIELECTRIC:
+      c[12] = m.u.dielectric.refraction_index;
+      return true;
+    default:
+      return false;
+  }
+}
+
+bool fill_cold(double* c, const TorHittableVariant& h, int64_t orig) {
+  if (h.kind == TOR_SPHERE) {
+    const TorSphere& s = h.u.sphere;
+    c[0] = s.center.x; c[1] = s.center.y; c[2] = s.center.z;
+    c[6] = 1.0 / s.radius;  // vec3s.nim:93-94: `/ radius` is `* (1.0 / radius)`
+    c[14] = i64_as_double(orig);
+    c[15] = s.radius * s.radius;  // spheres.nim:32 `self.radius*self.radius`
+    return fill_material(c, s.material, 0);
+  }
+  const TorMovingSphere& s = h.u.moving_sphere;
+  c[0] = s.center0.x; c[1] = s.center0.y; c[2] = s.center0.z;
+  c[3] = s.center1.x - s.center0.x; c[4] = s.center1.y - s.center0.y; c[5] = s.center1.z - s.center0.z;  // moving_spheres.nim:43
+  c[6] = 1.0 / s.radius;
+  c[7] = s.time0; c[8] = s.time1 - s.time0;  // moving_spheres.nim:42
+  c[14] = i64_as_double(orig);
+  c[15] = s.radius * s.radius;
+  return fill_material(c, s.material, 1);
+}
+
+}  // namespace
+
+// AoS -> SoA.  Objects are partitioned into one static segment and one segment per distinct
+// (time0, time1) pair; closest-hit is order independent (hittables_lists.nim:48-55; ties are broken
+// by the original index carried in the cold record), so the reordering is exact.
+bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& ids, HostLayout& out, std::string& err) {
+  std::vector<int64_t> statics;
+  std::vector<std::pair<std::pair<uint64_t, uint64_t>, std::vector<int64_t>>> groups;
+  for (int64_t i : ids) {
+    const TorHittableVariant& h = objs[i];
+    if (h.kind == TOR_SPHERE) {
+      statics.push_back(i);
+    } else if (h.kind == TOR_MOVING_SPHERE) {
+      uint64_t k0, k1;
+      std::memcpy(&k0, &h.u.moving_sphere.time0, 8);
+      std::memcpy(&k1, &h.u.moving_sphere.time1, 8);
+      bool found = false;
+      for (auto& g : groups)
+        if (g.first.first == k0 && g.first.second == k1) {
+          g.second.push_back(i);
+          found = true;
+          break;
+        }
+      if (!found) groups.push_back({{k0, k1}, {i}});
+    } else {
+      err = "unknown HittableVariant kind";
+      return false;
+    }
+  }
+  const size_t n_stat_p = padded(statics.size());
+  // a group moves "along y only" when every member has center1.x == center0.x and
+  // center1.z == center0.z: then c0 + f*(c1-c0) leaves x and z untouched, exactly
+  std::vector<char> yonly(groups.size(), 0);
+  size_t n_mov_p = 0, n_movy_p = 0;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    bool y = true;
+    for (int64_t idx : groups[gi].second) {
+      const TorMovingSphere& s = objs[idx].u.moving_sphere;
+      if (!(s.center1.x - s.center0.x == 0.0 && s.center1.z - s.center0.z == 0.0)) { y = false; break; }
+    }
+    yonly[gi] = y ? 1 : 0;
+    (y ? n_movy_p : n_mov_p) += padded(groups[gi].second.size());
+  }
+  out.n_sorted = n_stat_p + n_mov_p + n_movy_p;
+  // one record of slack behind every hot array: the object loop requests record k+1 while it
+  // works on record k
+  out.stat.assign(4 * n_stat_p + 8, 0.0);
+  out.mov.assign(8 * n_mov_p + 8, 0.0);
+  out.movy.assign(6 * n_movy_p + 8, 0.0);
+  out.cold.assign(16 * out.n_sorted + 16, 0.0);
+  out.segs.clear();
+  // padding record: centre 0, radius^2 = -1  => discriminant <= -|d|^2 < 0, never a candidate
+  for (size_t k = 0; k < n_stat_p; ++k) out.stat[4 * k + 3] = -1.0;
+  for (size_t k = 0; k < n_mov_p; ++k) out.mov[8 * k + 3] = -1.0;
+  for (size_t k = 0; k < n_movy_p; ++k) out.movy[6 * k + 3] = -1.0;
+  for (size_t k = 0; k < out.n_sorted; ++k) out.cold[16 * k + 15] = -1.0;
+
+  size_t sorted = 0;
+  if (!statics.empty()) {
+    out.segs.insert(out.segs.end(), {0.0, 0.0, (double)n_stat_p, 0.0, 0.0, 0.0, 0.0, 0.0});
+    for (size_t k = 0; k < statics.size(); ++k) {
+      const TorSphere& s = objs[statics[k]].u.sphere;
+      out.stat[4 * k + 0] = s.center.x; out.stat[4 * k + 1] = s.center.y; out.stat[4 * k + 2] = s.center.z;
+      out.stat[4 * k + 3] = s.radius * s.radius;
+      if (!fill_cold(&out.cold[16 * (sorted + k)], objs[statics[k]], statics[k])) { err = "unknown Material kind"; return false; }
+    }
+    sorted += n_stat_p;
+  }
+  size_t mov_rec = 0, movy_rec = 0;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    auto& g = groups[gi];
+    const size_t cnt_p = padded(g.second.size());
+    const TorMovingSphere& first = objs[g.second[0]].u.moving_sphere;
+    const double t0 = first.time0, dt = first.time1 - first.time0;
+    const bool y = yonly[gi] != 0;
+    out.segs.insert(out.segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)cnt_p,
+                                     (double)(sorted / kPad), t0, dt, 0.0, 0.0});
+    for (size_t k = 0; k < g.second.size(); ++k) {
+      const TorMovingSphere& s = objs[g.second[k]].u.moving_sphere;
+      const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
+      if (y) {
+        double* m = &out.movy[6 * (movy_rec + k)];
+        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+        m[3] = s.radius * s.radius;
+        m[4] = dcy;
+      } else {
+        double* m = &out.mov[8 * (mov_rec + k)];
+        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+        m[3] = s.radius * s.radius;
+        m[4] = dcx; m[5] = dcy; m[6] = dcz;
+      }
+      if (!fill_cold(&out.cold[16 * (sorted + k)], objs[g.second[k]], g.second[k])) { err = "unknown Material kind"; return false; }
+    }
+    (y ? movy_rec : mov_rec) += cnt_p;
+    sorted += cnt_p;
+  }
+  out.n_segs = (int)(out.segs.size() / 8);
+  if (out.segs.empty()) out.segs.assign(8, 0.0);
+  return true;
+}
+
+namespace {
+
+uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3ff;
+  v = (v | (v << 16)) & 0x030000FF;
+  v = (v | (v << 8)) & 0x0300F00F;
+  v = (v | (v << 4)) & 0x030C30C3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+
+bool finite3(const TorVec3& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
+
+}  // namespace
+
+void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
+  out = HostAccel{};
+  if (n < 64) return;  // not worth a second level
+  // radius of the typical object
+  std::vector<double> radii;
+  radii.reserve((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const double r = objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.radius : objs[i].u.moving_sphere.radius;
+    radii.push_back(std::fabs(r));
+  }
+  std::vector<double> tmp = radii;
+  std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+  const double median_r = tmp[tmp.size() / 2];
+  std::vector<int64_t> always, spatial;
+  for (int64_t i = 0; i < n; ++i) {
+    bool ok = std::isfinite(radii[(size_t)i]) && radii[(size_t)i] <= 2.5 * median_r;
+    if (objs[i].kind == TOR_SPHERE) {
+      ok = ok && finite3(objs[i].u.sphere.center);
+    } else if (objs[i].kind == TOR_MOVING_SPHERE) {
+      const TorMovingSphere& s = objs[i].u.moving_sphere;
+      const double dt = s.time1 - s.time0;
+      ok = ok && finite3(s.center0) && finite3(s.center1) && std::isfinite(s.time0) && std::isfinite(dt) && dt != 0.0;
+    } else {
+      return;  // unknown kind: the brute-force upload reports it
+    }
+    (ok ? spatial : always).push_back(i);
+  }
+  if (spatial.size() < 32) return;
+  std::string err;
+  if (!build_layout(objs, always, out.always, err)) return;
+  // Morton order over the spatial objects' (start) centres
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  auto c0 = [&](int64_t i, int a) {
+    const TorVec3& c = objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.center : objs[i].u.moving_sphere.center0;
+    return a == 0 ? c.x : (a == 1 ? c.y : c.z);
+  };
+  for (int64_t i : spatial)
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c0(i, a)); hi[a] = std::max(hi[a], c0(i, a)); }
+  double ext = 1e-300;
+  for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+  std::vector<std::pair<uint32_t, int64_t>> keyed;
+  keyed.reserve(spatial.size());
+  for (int64_t i : spatial) {
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) q[a] = (uint32_t)std::min(1023.0, std::max(0.0, (c0(i, a) - lo[a]) / ext * 1023.0));
+    keyed.push_back({spread10(q[0]) | (spread10(q[2]) << 1) | (spread10(q[1]) << 2), i});
+  }
+  std::stable_sort(keyed.begin(), keyed.end());
+  out.n_blocks = (keyed.size() + kPad - 1) / kPad;
+  out.spatial_base = out.always.n_sorted;
+  out.cold = out.always.cold;
+  // cold slots for every bound slot of the (padded) bounds segment, all never-hit until filled
+  const size_t n_bnd_slots = (out.n_blocks + kPad - 1) / kPad * kPad;
+  out.cold.resize(16 * (out.spatial_base + n_bnd_slots * kPad) + 16, 0.0);
+  out.spatial.assign(out.n_blocks * kPad, HostAccel::Obj{});
+  for (size_t k = 0; k < n_bnd_slots * kPad; ++k) out.cold[16 * (out.spatial_base + k) + 15] = -1.0;
+  for (size_t k = 0; k < keyed.size(); ++k) {
+    const int64_t i = keyed[k].second;
+    double* c = &out.cold[16 * (out.spatial_base + k)];
+    std::fill(c, c + 16, 0.0);
+    if (!fill_cold(c, objs[i], i)) { out = HostAccel{}; return; }
+    HostAccel::Obj& o = out.spatial[k];
+    o.valid = true;
+    o.moving = objs[i].kind == TOR_MOVING_SPHERE;
+    for (int a = 0; a < 3; ++a) { o.c0[a] = c[a]; o.dc[a] = c[3 + a]; }
+    o.t0 = c[7]; o.dt = c[8];
+    o.abs_r = radii[(size_t)i];
+  }
+  // the bounds segment (kind 3): records live in KParams.bnd, one per block, padded to 8
+  const size_t n_bnd_p = (out.n_blocks + kPad - 1) / kPad * kPad;
+  if (out.always.n_segs == 0) out.always.segs.clear();
+  out.always.segs.insert(out.always.segs.end(), {3.0, 0.0, (double)n_bnd_p, 0.0, 0.0, 0.0, 0.0, 0.0});
+  out.always.n_segs += 1;
+  out.available = true;
+}
+
+bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::vector<double>& bnd) {
+  if (!std::isfinite(t_lo) || !std::isfinite(t_hi)) return false;
+  const size_t n_bnd_p = (acc.n_blocks + kPad - 1) / kPad * kPad;
+  bnd.assign(8 * n_bnd_p + 16, 0.0);
+  // padding / empty block: NaN bounds.  Every slab product is NaN, v_min/v_max drop NaN operands, so
+  // t_in = 0 and t_out = NaN and `t_in <= t_out` is false.  (An inverted box would NOT do: the slab
+  // test is symmetric in lo/hi.)  The cold slots behind padding bounds hold never-hit records anyway.
+  const double qnan = std::nan("");
+  for (size_t b = 0; b < n_bnd_p + 1; ++b)
+    for (int a = 0; a < 6; ++a) bnd[8 * b + a] = qnan;
+  for (size_t b = 0; b < acc.n_blocks; ++b) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool any = false;
+    for (int j = 0; j < kPad; ++j) {
+      const HostAccel::Obj& o = acc.spatial[b * kPad + j];
+      if (!o.valid) continue;
+      // the centre moves linearly in t: the swept sphere lies in the hull of its two end positions
+      const int ends = o.moving ? 2 : 1;
+      for (int e = 0; e < ends; ++e) {
+        const double f = o.moving ? ((e == 0 ? t_lo : t_hi) - o.t0) / o.dt : 0.0;
+        if (!std::isfinite(f)) return false;
+        for (int a = 0; a < 3; ++a) {
+          const double c = o.c0[a] + f * o.dc[a];
+          lo[a] = std::min(lo[a], c - o.abs_r);
+          hi[a] = std::max(hi[a], c + o.abs_r);
+        }
+      }
+      any = true;
+    }
+    if (!any) continue;
+    for (int a = 0; a < 3; ++a) {
+      // inflate far beyond any rounding of the float64 slab test (relative 1e-6 vs ~1e-15)
+      const double pad = 1e-6 * (1.0 + std::fabs(lo[a]) + std::fabs(hi[a]) + (hi[a] - lo[a]));
+      if (!std::isfinite(pad)) return false;
+      bnd[8 * b + a] = lo[a] - pad;
+      bnd[8 * b + 3 + a] = hi[a] + pad;
+    }
+  }
+  return true;
+}
+
+}  // namespace tor

@@ -1,0 +1,45 @@
+// tor_scene.hpp -- host-side flattening of the reference's AoS object list
+// (hittables_lists.nim:15-46, HittableVariant hittables_variants.nim:50-57) into the device layouts
+// described in tor_kernels.hpp, and the optional block-bounds acceleration layout.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/tor_render.h"
+
+namespace tor {
+
+// Brute-force layout of a subset of the objects (tor_kernels.hpp: stat / movy / mov / segs / cold).
+struct HostLayout {
+  std::vector<double> stat, mov, movy, segs, cold;
+  int n_segs = 0;
+  size_t n_sorted = 0;  // cold slots (padded)
+};
+
+// Builds the layout for objects `ids` (original indices, kept in this order inside each segment).
+// Returns false and sets err for unknown kinds.
+bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& ids, HostLayout& out, std::string& err);
+
+// Acceleration layout (TOR_ACCEL_BLOCKS): large or irregular objects stay in an "always" brute-force
+// layout; the rest are sorted along a Morton curve and cut into blocks of 8 consecutive objects.
+// Per render call the blocks get conservative bounding spheres (they depend on the ray-time range).
+struct HostAccel {
+  bool available = false;
+  HostLayout always;            // + one segment of kind 3 (the bounds) appended to always.segs
+  std::vector<double> cold;     // always.cold followed by the spatial objects' cold records
+  size_t spatial_base = 0;      // first cold slot of the spatial objects (multiple of 8)
+  size_t n_blocks = 0;
+  struct Obj { double c0[3], dc[3], t0, dt, abs_r; bool moving, valid; };
+  std::vector<Obj> spatial;     // n_blocks * 8 entries (padding: valid = false)
+};
+
+void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out);
+
+// 8 float64 per block {lo xyz, hi xyz, 0, 0}: a conservative (inflated) axis-aligned box around the
+// block's spheres over the ray-time range; padded to a multiple of 8 blocks with never-entered boxes.
+// Returns false when the time range is not finite (caller falls back to brute force).
+bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::vector<double>& bnd);
+
+}  // namespace tor
