@@ -83,7 +83,7 @@ struct TorContext {
   DeviceBuffer stat, mov, movy, segs, cold;
   // TOR_ACCEL_BLOCKS layout: always-list + spatial blocks; bounds travel per launch (ring)
   tor::HostAccel accel;
-  DeviceBuffer a_stat, a_mov, a_movy, a_segs, a_cold, bnd_ring;
+  DeviceBuffer a_stat, a_mov, a_movy, a_segs, a_cold, a_hot, a_grp, bnd_ring;
   size_t bnd_slot_bytes = 0;
   int n_segs = 0;
   int64_t n_objects = 0;
@@ -105,13 +105,13 @@ struct TorContext {
   // Launch shape, measured on MI355X (profiles/r1_wave_service.txt): waves that share a SIMD get
   // very unequal service (hardware slot 0 ~38 us per bounce iteration, slot 4 0.6-2 ms), so
   // extra waves add little throughput and park work in slow waves.  Per seeding mode:
-  //   SAMPLE: 128-VGPR kernel (no spills), 3 workgroups/CU  -> best throughput
-  //   PIXEL : 2 workgroups/CU: a pixel is a sequential chain of spp samples, every wave that
-  //           holds one must get good service
-  // Overridable for experiments: TOR_WAVES_PER_SIMD (4|5), TOR_BLOCKS_PER_CU.
+  //   SAMPLE: 3 workgroups/CU (kernel compiled for <= 168 VGPRs)  -> best throughput
+  //   PIXEL : 2 workgroups/CU (<= 256 VGPRs): a pixel is a sequential chain of spp samples, every
+  //           wave that holds one must get good service
+  // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3|4), TOR_BLOCKS_PER_CU.
   int max_blocks_per_cu[2] = {2, 3};  // [seeding]
   int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
-  int waves_per_simd = 4;  // register budget variant of the integrator (4: 128 VGPR, 5: 96 VGPR)
+  int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3|4): force a register-budget variant of the kernel
 };
 
 namespace {
@@ -174,7 +174,7 @@ int tor_context_create(int32_t device, TorContext** out) {
     return fail_hip(e, "hipGetDeviceProperties");
   }
   ctx->num_cus = prop.multiProcessorCount;
-  if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_per_simd = (std::atoi(w) >= 5) ? 5 : 4;
+  if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
   if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU")) ctx->max_blocks_per_cu[0] = ctx->max_blocks_per_cu[1] = std::atoi(b);
   e = ctx->counters.ensure(8 * sizeof(unsigned long long));
@@ -200,7 +200,7 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->segs.release();
   ctx->cold.release();
   ctx->a_stat.release(); ctx->a_mov.release(); ctx->a_movy.release(); ctx->a_segs.release();
-  ctx->a_cold.release(); ctx->bnd_ring.release();
+  ctx->a_cold.release(); ctx->a_hot.release(); ctx->a_grp.release(); ctx->bnd_ring.release();
   ctx->counters.release();
   ctx->cam_ring.release();
   ctx->wave_log.release();
@@ -255,6 +255,8 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
     HIP_TRY(put(ctx->a_movy, ctx->accel.always.movy));
     HIP_TRY(put(ctx->a_segs, ctx->accel.always.segs));
     HIP_TRY(put(ctx->a_cold, ctx->accel.cold));
+    HIP_TRY(put(ctx->a_hot, ctx->accel.hot));
+    HIP_TRY(put(ctx->a_grp, ctx->accel.groups));
     const size_t n_bnd_p = (ctx->accel.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
     ctx->bnd_slot_bytes = (8 * n_bnd_p + 16) * 8;
     HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
@@ -309,8 +311,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   }
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
+  const int cap = ctx->max_blocks_per_cu[o.seeding];
+  const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
   int& bpc = ctx->blocks_per_cu[o.seeding][o.arith];
-  if (bpc == 0) bpc = tor::integrate_blocks_per_cu(o.seeding, o.arith, ctx->waves_per_simd);
+  if (bpc == 0) bpc = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd);
   if (ctx->max_blocks_per_cu[o.seeding] > 0 && bpc > ctx->max_blocks_per_cu[o.seeding]) bpc = ctx->max_blocks_per_cu[o.seeding];
   const long long resident_waves = (long long)ctx->num_cus * bpc * (tor::kThreads / 64);
 
@@ -323,6 +327,9 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.n_segs = ctx->n_segs;
   p.bnd = nullptr;
   p.spatial_base = 0;
+  p.shot = nullptr;
+  p.sgrp = nullptr;
+  p.shot_lds_doubles = 0;
   std::vector<double> bnd_host;
   bool use_accel = false;
   if (o.accel == TOR_ACCEL_BLOCKS && ctx->accel.available) {
@@ -339,6 +346,14 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.cold = (const double*)ctx->a_cold.ptr;
     p.n_segs = ctx->accel.always.n_segs;
     p.spatial_base = (int)ctx->accel.spatial_base;
+    p.shot = (const double*)ctx->a_hot.ptr;
+    p.sgrp = (const double*)ctx->a_grp.ptr;
+    // LDS staging of the compact records: up to ~34 KB per workgroup keeps 3 workgroups per CU
+    // (3 x (18 KB queues + 34 KB) < 160 KB)
+    const size_t hot_doubles = ctx->accel.hot.size();
+    const char* st = std::getenv("TOR_STAGE_LDS");
+    const size_t cap = st ? (size_t)std::atoll(st) : 34816;
+    p.shot_lds_doubles = (hot_doubles * 8 <= cap) ? (int)hot_doubles : 0;
   }
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
   p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
@@ -409,7 +424,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     HIP_TRY(tor::launch_tile_order((const unsigned*)ctx->tile_cost.ptr, (unsigned*)ctx->tile_order.ptr, (int)n_tiles, stream));
     p.order = (const unsigned*)ctx->tile_order.ptr;
   }
-  HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, ctx->waves_per_simd, blocks, stream));
+  HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));
   HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
   ctx->launches += 1;
   ctx->timing_valid = true;

@@ -139,6 +139,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const double h_div = (double)(p.nrows - 1);
   constexpr bool kProbe = (SEEDING == 2);  // cost probe for the SEED_PIXEL tile schedule
 
+  // TOR_ACCEL_BLOCKS: the block expansion gathers 8 x 64 B per lane and trip with 64 different
+  // addresses; when the compact records fit they are staged in LDS once per workgroup.
+  const double* shot = p.shot;
+  if (p.shot_lds_doubles > 0) {
+    double* stage = reinterpret_cast<double*>(smem_raw + (kThreads / 64) * kWaveLdsBytes);
+    for (int k = threadIdx.x; k < p.shot_lds_doubles; k += kThreads) stage[k] = p.shot[k];
+    __syncthreads();
+    shot = stage;
+  }
+
   if (SEEDING == 1) {
     if (lane < kAccSlots) {
       tag_lds[lane] = -1;
@@ -391,81 +401,110 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         }
 
         // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
-        // Queue entries are 8-bit masks over a block of 8 consecutive cold slots (direct candidates)
-        // or, flagged with bit 31, over 8 block bounds: each set bit of those expands to the 8
-        // objects of that spatial block.  One object per lane per trip of the loop.
+        // Queue entries are 8-bit masks over 8 consecutive cold slots (direct candidates) or, flagged
+        // with bit 31, over 8 block bounds.  A trip of the loop handles one set bit per lane: either
+        // one object, or one spatial block of 8 objects (an unrolled discriminant/filter stage over
+        // the block's compact records, then exact roots for the few that pass).
+        int f_gid = -1;      // time group whose fraction f_val = (time - time0)/(time1 - time0) is cached
+        double f_val = 0.0;  // (moving_spheres.nim:42; identical for every member of a time group)
+        // exact part of hit(): spheres.nim:35-48 with t_min = 0.001 and the order-independent update
+        auto exact_hit = [&](double cx, double cy, double cz, double r2, unsigned idx, double f) {
+          const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+          double hb, cc, disc;
+          if (ARITH == 0) {
+            hb = ocx * dx + ocy * dy + ocz * dz;
+            cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+            disc = hb * hb - a * cc;
+          } else {
+            hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+            cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
+            disc = fma_(hb, hb, -(a * cc));
+          }
+          if (disc > 0.0) {
+            const double root = __builtin_sqrt(disc);
+            double sol = (-hb - root) / a;
+            bool ok = (0.001 < sol) && (sol < __builtin_inf());
+            if (!ok) {
+              sol = (-hb + root) / a;
+              ok = (0.001 < sol) && (sol < __builtin_inf());
+            }
+            if (ok) {
+              const int orig = (int)__double_as_longlong(p.cold[(size_t)idx * 16 + 14]);
+              if (sol < best_t || (sol == best_t && orig < best_orig)) {
+                best_t = sol;
+                best_idx = (int)idx;
+                best_orig = orig;
+                best_f = f;
+              }
+            }
+          }
+        };
+        // centre of a spatial object from its compact record {c0 xyz, r^2, dc xyz, group id | -1}
+        auto spatial_center = [&](const double* hrec, double& cx, double& cy, double& cz, double& f) {
+          cx = hrec[0]; cy = hrec[1]; cz = hrec[2];
+          f = 0.0;
+          const int gid = (int)hrec[7];
+          if (gid >= 0) {
+            if (gid != f_gid) {
+              f_val = (time - p.sgrp[2 * gid]) / p.sgrp[2 * gid + 1];
+              f_gid = gid;
+            }
+            f = f_val;
+            if (ARITH == 0) {
+              cx = cx + hrec[4] * f; cy = cy + hrec[5] * f; cz = cz + hrec[6] * f;
+            } else {
+              cx = fma_(hrec[4], f, cx); cy = fma_(hrec[5], f, cy); cz = fma_(hrec[6], f, cz);
+            }
+          }
+        };
         unsigned kq = 0, cur_mask = 0, cur_block = 0, cur_is_bound = 0;
-        unsigned exp_left = 0, exp_idx = 0;
         for (;;) {
-          if (exp_left == 0 && cur_mask == 0 && kq < qn) {
+          if (cur_mask == 0 && kq < qn) {
             const unsigned e = q[kq * 64];
             kq += 1;
             cur_is_bound = e >> 31;
             cur_block = (e >> 8) & 0x7fffffu;
             cur_mask = e & 0xffu;
           }
-          const bool has = (exp_left != 0) || (cur_mask != 0);
+          const bool has = cur_mask != 0;
           if (ballot64(has) == 0) break;
           if (has) {
-            unsigned idx;
-            if (exp_left != 0) {
-              idx = exp_idx;
-              exp_idx += 1;
-              exp_left -= 1;
+            const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> record j of the group
+            cur_mask &= ~(1u << b);
+            const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
+            if (cur_is_bound) {
+              // ---- spatial block `rec`: filter its 8 objects, then exact roots for the survivors
+              const double* blk = shot + (size_t)rec * (8 * kBlock);
+              unsigned m8 = 0;
+#pragma unroll
+              for (int j = 0; j < kBlock; ++j) {
+                double cx, cy, cz, f;
+                spatial_center(blk + 8 * j, cx, cy, cz, f);
+                m8 = push_bit(m8, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, blk[8 * j + 3]));
+              }
+              st_cand += kBlock;
+              while (m8 != 0) {
+                const int bb = 31 - __builtin_clz(m8);
+                m8 &= ~(1u << bb);
+                const int j = 7 - bb;
+                double cx, cy, cz, f;
+                spatial_center(blk + 8 * j, cx, cy, cz, f);
+                exact_hit(cx, cy, cz, blk[8 * j + 3], (unsigned)p.spatial_base + rec * kBlock + (unsigned)j, f);
+              }
             } else {
-              const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> record j of the group
-              cur_mask &= ~(1u << b);
-              const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
-              if (cur_is_bound) {
-                idx = (unsigned)p.spatial_base + rec * kBlock;  // first object of spatial block `rec`
-                exp_idx = idx + 1;
-                exp_left = kBlock - 1;
-              } else {
-                idx = rec;
-              }
-            }
-            st_cand += 1;
-            const double* c = p.cold + (size_t)idx * 16;
-            const double c0x = c[0], c0y = c[1], c0z = c[2];
-            const double r2 = c[15];
-            const int flags = (int)__double_as_longlong(c[13]);
-            double cx = c0x, cy = c0y, cz = c0z, f = 0.0;
-            if (flags & 1) {
-              f = (time - c[7]) / c[8];
-              if (ARITH == 0) {
-                cx = c0x + c[3] * f; cy = c0y + c[4] * f; cz = c0z + c[5] * f;
-              } else {
-                cx = fma_(c[3], f, c0x); cy = fma_(c[4], f, c0y); cz = fma_(c[5], f, c0z);
-              }
-            }
-            const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-            double hb, cc, disc;
-            if (ARITH == 0) {
-              hb = ocx * dx + ocy * dy + ocz * dz;
-              cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
-              disc = hb * hb - a * cc;
-            } else {
-              hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
-              cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
-              disc = fma_(hb, hb, -(a * cc));
-            }
-            if (disc > 0.0) {
-              const double root = __builtin_sqrt(disc);
-              double sol = (-hb - root) / a;
-              bool ok = (0.001 < sol) && (sol < __builtin_inf());
-              if (!ok) {
-                sol = (-hb + root) / a;
-                ok = (0.001 < sol) && (sol < __builtin_inf());
-              }
-              if (ok) {
-                const int orig = (int)__double_as_longlong(c[14]);
-                if (sol < best_t || (sol == best_t && orig < best_orig)) {
-                  best_t = sol;
-                  best_idx = (int)idx;
-                  best_orig = orig;
-                  best_f = f;
+              st_cand += 1;
+              const double* c = p.cold + (size_t)rec * 16;
+              double cx = c[0], cy = c[1], cz = c[2], f = 0.0;
+              const int flags = (int)__double_as_longlong(c[13]);
+              if (flags & 1) {
+                f = (time - c[7]) / c[8];
+                if (ARITH == 0) {
+                  cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f;
+                } else {
+                  cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz);
                 }
               }
+              exact_hit(cx, cy, cz, c[15], rec, f);
             }
           }
         }
@@ -671,7 +710,7 @@ __global__ void selftest_kernel(int op, const double* x, const double* y, double
 // ---------------------------------------------------------------------------------------
 template <int W>
 static hipError_t launch_integrate_w(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream) {
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
   dim3 grid((unsigned)blocks), block(kThreads);
   if (seeding == 0 && arith == 0) hipLaunchKernelGGL((integrate_kernel<0, 0, W>), grid, block, smem, stream, p);
   else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1, W>), grid, block, smem, stream, p);
@@ -681,8 +720,8 @@ static hipError_t launch_integrate_w(const KParams& p, int seeding, int arith, i
 }
 
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
-  hipLaunchKernelGGL((integrate_kernel<2, 0, 4>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
+  hipLaunchKernelGGL((integrate_kernel<2, 0, 3>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
   return hipGetLastError();
 }
 
@@ -693,7 +732,9 @@ hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles,
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream) {
-  if (waves_per_simd >= 5) return launch_integrate_w<5>(p, seeding, arith, blocks, stream);
+  // register budget follows the launch shape: 2 workgroups/CU -> 256 VGPRs, 3 -> 168, 4 -> 128
+  if (waves_per_simd <= 2) return launch_integrate_w<2>(p, seeding, arith, blocks, stream);
+  if (waves_per_simd == 3) return launch_integrate_w<3>(p, seeding, arith, blocks, stream);
   return launch_integrate_w<4>(p, seeding, arith, blocks, stream);
 }
 
@@ -711,7 +752,9 @@ static int blocks_per_cu_w(int seeding, int arith) {
 }
 
 int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd) {
-  return waves_per_simd >= 5 ? blocks_per_cu_w<5>(seeding, arith) : blocks_per_cu_w<4>(seeding, arith);
+  if (waves_per_simd <= 2) return blocks_per_cu_w<2>(seeding, arith);
+  if (waves_per_simd == 3) return blocks_per_cu_w<3>(seeding, arith);
+  return blocks_per_cu_w<4>(seeding, arith);
 }
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {

@@ -231,11 +231,30 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
   out.cold.resize(16 * (out.spatial_base + n_bnd_slots * kPad) + 16, 0.0);
   out.spatial.assign(out.n_blocks * kPad, HostAccel::Obj{});
   for (size_t k = 0; k < n_bnd_slots * kPad; ++k) out.cold[16 * (out.spatial_base + k) + 15] = -1.0;
+  out.hot.assign(8 * n_bnd_slots * kPad + 8, 0.0);
+  out.groups.clear();
+  for (size_t k = 0; k < n_bnd_slots * kPad; ++k) { out.hot[8 * k + 3] = -1.0; out.hot[8 * k + 7] = -1.0; }
   for (size_t k = 0; k < keyed.size(); ++k) {
     const int64_t i = keyed[k].second;
     double* c = &out.cold[16 * (out.spatial_base + k)];
     std::fill(c, c + 16, 0.0);
     if (!fill_cold(c, objs[i], i)) { out = HostAccel{}; return; }
+    // compact record the block expansion reads: {c0 xyz, r^2, dc xyz, time-group id (-1: static)}
+    double* hrec = &out.hot[8 * k];
+    hrec[0] = c[0]; hrec[1] = c[1]; hrec[2] = c[2]; hrec[3] = c[15];
+    hrec[4] = c[3]; hrec[5] = c[4]; hrec[6] = c[5];
+    hrec[7] = -1.0;
+    if (objs[i].kind == TOR_MOVING_SPHERE) {
+      size_t g = 0;
+      for (; g < out.groups.size() / 2; ++g) {
+        uint64_t a0, a1, b0, b1;
+        std::memcpy(&a0, &out.groups[2 * g], 8); std::memcpy(&a1, &out.groups[2 * g + 1], 8);
+        std::memcpy(&b0, &c[7], 8); std::memcpy(&b1, &c[8], 8);
+        if (a0 == b0 && a1 == b1) break;
+      }
+      if (g == out.groups.size() / 2) { out.groups.push_back(c[7]); out.groups.push_back(c[8]); }
+      hrec[7] = (double)g;
+    }
     HostAccel::Obj& o = out.spatial[k];
     o.valid = true;
     o.moving = objs[i].kind == TOR_MOVING_SPHERE;
@@ -248,6 +267,7 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
   if (out.always.n_segs == 0) out.always.segs.clear();
   out.always.segs.insert(out.always.segs.end(), {3.0, 0.0, (double)n_bnd_p, 0.0, 0.0, 0.0, 0.0, 0.0});
   out.always.n_segs += 1;
+  if (out.groups.empty()) out.groups.assign(2, 1.0);
   out.available = true;
 }
 
