@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
                     help="c2: random_scene frame (default, the metric's config); c5: BASELINE configs[4], the animated "
                          "bouncing-spheres scene, 256 spp per frame, frames dealt round-robin to the GPUs (no collective)")
+    ap.add_argument("--no-accel-leg", action="store_true", help="skip the secondary TOR_ACCEL_BLOCKS measurement")
     ap.add_argument("--stats", action="store_true", help="also collect the kernel's workload counters (untimed extra step)")
     return ap.parse_args()
 
@@ -270,6 +271,23 @@ def main():
                                       (" + RCCL all_gather of the framebuffer" if world > 1 else "")},
             "roofline": roof,
         }
+    if rank == 0 and world == 1 and args.accel == "none" and not args.no_accel_leg:
+        # secondary leg (never the metric's value): the same frame with TOR_ACCEL_BLOCKS -- exact block
+        # culling, bit-identical canvas (tests/test_gpu_parity.py::test_block_culling_never_changes_a_pixel)
+        opt2 = tor.make_options(seeding=seeding, arith=arith, row_tile=args.row_tile, accel=tor.ACCEL_BLOCKS)
+        ref_frame = frame.shard.clone()
+        ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref_frame, frame.shard))
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        result["accel_blocks"] = {"value": round(total_samples * args.steps / dt2 / 1e6, 2), "unit": "Msamples/s",
+                                  "ms_per_step": round(dt2 / args.steps * 1e3, 3), "canvas_identical_to_brute_force": same,
+                                  "note": "SURVEY 8 f4: spatial blocks of 8 objects behind conservative boxes; the metric's "
+                                          "value above is the reference's brute-force closest hit"}
     if args.stats and rank == 0:
         ctx.set_stats(True)
         step()
