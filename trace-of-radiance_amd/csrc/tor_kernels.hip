@@ -42,6 +42,8 @@ namespace tor {
 
 // scalar (constant address space) view of the read-only scene so the compiler emits s_load
 typedef const double __attribute__((address_space(4))) * cdptr;
+typedef const double __attribute__((address_space(3))) * ldptr;  // LDS
+typedef const double __attribute__((address_space(1))) * gdptr;  // global
 
 __device__ __forceinline__ cdptr as_const(const double* p) { return (cdptr)(uintptr_t)p; }
 
@@ -141,12 +143,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
   // TOR_ACCEL_BLOCKS: the block expansion gathers 8 x 64 B per lane and trip with 64 different
   // addresses; when the compact records fit they are staged in LDS once per workgroup.
-  const double* shot = p.shot;
-  if (p.shot_lds_doubles > 0) {
-    double* stage = reinterpret_cast<double*>(smem_raw + (kThreads / 64) * kWaveLdsBytes);
+  const bool staged = p.shot_lds_doubles > 0;
+  double* stage = reinterpret_cast<double*>(smem_raw + (kThreads / 64) * kWaveLdsBytes);
+  const ldptr shot_lds = (ldptr)stage;
+  if (staged) {
     for (int k = threadIdx.x; k < p.shot_lds_doubles; k += kThreads) stage[k] = p.shot[k];
     __syncthreads();
-    shot = stage;
   }
 
   if (SEEDING == 1) {
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
         };
         // centre of a spatial object from its compact record {c0 xyz, r^2, dc xyz, group id | -1}
-        auto spatial_center = [&](const double* hrec, double& cx, double& cy, double& cz, double& f) {
+        auto spatial_center = [&](auto hrec, double& cx, double& cy, double& cz, double& f) {
           cx = hrec[0]; cy = hrec[1]; cz = hrec[2];
           f = 0.0;
           const int gid = (int)hrec[7];
@@ -474,23 +476,26 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
             if (cur_is_bound) {
               // ---- spatial block `rec`: filter its 8 objects, then exact roots for the survivors
-              const double* blk = shot + (size_t)rec * (8 * kBlock);
-              unsigned m8 = 0;
+              auto expand = [&](auto blk) {
+                unsigned m8 = 0;
 #pragma unroll
-              for (int j = 0; j < kBlock; ++j) {
-                double cx, cy, cz, f;
-                spatial_center(blk + 8 * j, cx, cy, cz, f);
-                m8 = push_bit(m8, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, blk[8 * j + 3]));
-              }
+                for (int j = 0; j < kBlock; ++j) {
+                  double cx, cy, cz, f;
+                  spatial_center(blk + 8 * j, cx, cy, cz, f);
+                  m8 = push_bit(m8, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, blk[8 * j + 3]));
+                }
+                while (m8 != 0) {
+                  const int bb = 31 - __builtin_clz(m8);
+                  m8 &= ~(1u << bb);
+                  const int j = 7 - bb;
+                  double cx, cy, cz, f;
+                  spatial_center(blk + 8 * j, cx, cy, cz, f);
+                  exact_hit(cx, cy, cz, blk[8 * j + 3], (unsigned)p.spatial_base + rec * kBlock + (unsigned)j, f);
+                }
+              };
               st_cand += kBlock;
-              while (m8 != 0) {
-                const int bb = 31 - __builtin_clz(m8);
-                m8 &= ~(1u << bb);
-                const int j = 7 - bb;
-                double cx, cy, cz, f;
-                spatial_center(blk + 8 * j, cx, cy, cz, f);
-                exact_hit(cx, cy, cz, blk[8 * j + 3], (unsigned)p.spatial_base + rec * kBlock + (unsigned)j, f);
-              }
+              if (staged) expand(shot_lds + (size_t)rec * (8 * kBlock));   // ds_read
+              else expand((gdptr)(uintptr_t)p.shot + (size_t)rec * (8 * kBlock));  // global_load
             } else {
               st_cand += 1;
               const double* c = p.cold + (size_t)rec * 16;
