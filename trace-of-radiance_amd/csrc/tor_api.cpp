@@ -101,7 +101,6 @@ struct TorContext {
   bool timing_valid = false;
   int64_t last_samples = 0;
   int64_t last_n_waves = 0;
-  int blocks_per_cu[2][2] = {{0, 0}, {0, 0}};
   // Launch shape, measured on MI355X (profiles/r1_wave_service.txt): waves that share a SIMD get
   // very unequal service (hardware slot 0 ~38 us per bounce iteration, slot 4 0.6-2 ms), so
   // extra waves add little throughput and park work in slow waves.  Per seeding mode:
@@ -311,13 +310,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   }
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
-  const int cap = ctx->max_blocks_per_cu[o.seeding];
-  const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
-  int& bpc = ctx->blocks_per_cu[o.seeding][o.arith];
-  if (bpc == 0) bpc = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd);
-  if (ctx->max_blocks_per_cu[o.seeding] > 0 && bpc > ctx->max_blocks_per_cu[o.seeding]) bpc = ctx->max_blocks_per_cu[o.seeding];
-  const long long resident_waves = (long long)ctx->num_cus * bpc * (tor::kThreads / 64);
-
   tor::KParams p{};
   p.stat = (const double*)ctx->stat.ptr;
   p.mov = (const double*)ctx->mov.ptr;
@@ -330,8 +322,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.shot = nullptr;
   p.sgrp = nullptr;
   p.shot_lds_doubles = 0;
+  p.shot_stride = 8;
   std::vector<double> bnd_host;
   bool use_accel = false;
+  int stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
   if (o.accel == TOR_ACCEL_BLOCKS && ctx->accel.available) {
     // rays carry the camera's shutter times, or 0 after a metal / dielectric bounce (rays.nim:19)
     const double t_lo = std::fmin(0.0, std::fmin(cam->shutter_open, cam->shutter_close));
@@ -348,13 +342,27 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.spatial_base = (int)ctx->accel.spatial_base;
     p.shot = (const double*)ctx->a_hot.ptr;
     p.sgrp = (const double*)ctx->a_grp.ptr;
-    // LDS staging of the compact records: up to ~34 KB per workgroup keeps 3 workgroups per CU
-    // (3 x (18 KB queues + 34 KB) < 160 KB)
-    const size_t hot_doubles = ctx->accel.hot.size();
+    p.shot_stride = ctx->accel.hot_stride;
+    // LDS staging of the compact records next to the per-wave queues (18 KB per workgroup, 160 KB per
+    // CU): it must fit at this mode's workgroups/CU, else one workgroup fewer, else global loads.
+    const size_t hot_bytes = ctx->accel.hot.size() * 8;
     const char* st = std::getenv("TOR_STAGE_LDS");
-    const size_t cap = st ? (size_t)std::atoll(st) : 34816;
-    p.shot_lds_doubles = (hot_doubles * 8 <= cap) ? (int)hot_doubles : 0;
+    const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
+    int& wg = stage_wg;
+    wg = 0;
+    for (int tryw = ctx->max_blocks_per_cu[o.seeding]; tryw >= 2 && wg == 0; --tryw)
+      if (hot_bytes <= hard_cap && hot_bytes + 18432 <= (size_t)(160 * 1024) / (size_t)tryw - 1024) wg = tryw;
+    p.shot_lds_doubles = wg > 0 ? (int)ctx->accel.hot.size() : 0;
   }
+  // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
+  // kernel variant's register budget follows it
+  int cap = ctx->max_blocks_per_cu[o.seeding];
+  if (cap < 1) cap = 4;
+  if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
+  const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
+  int bpc_eff = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd);
+  if (bpc_eff > cap) bpc_eff = cap;
+  const long long resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
   p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
   p.work_counter = (unsigned long long*)ctx->counters.ptr;

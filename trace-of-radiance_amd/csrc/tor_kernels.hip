@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "tor_device.hpp"
 #include "tor_kernels.hpp"
@@ -442,10 +443,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
         };
         // centre of a spatial object from its compact record {c0 xyz, r^2, dc xyz, group id | -1}
-        auto spatial_center = [&](auto hrec, double& cx, double& cy, double& cz, double& f) {
+        // HS = float64 per record: 8, or 4 for an all-static set (no dc / group fields)
+        auto spatial_center = [&](auto hrec, auto HS, double& cx, double& cy, double& cz, double& f) {
+          constexpr int hs = decltype(HS)::value;
           cx = hrec[0]; cy = hrec[1]; cz = hrec[2];
           f = 0.0;
-          const int gid = (int)hrec[7];
+          const int gid = (hs == 8) ? (int)hrec[7] : -1;
           if (gid >= 0) {
             if (gid != f_gid) {
               f_val = (time - p.sgrp[2 * gid]) / p.sgrp[2 * gid + 1];
@@ -476,26 +479,34 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
             if (cur_is_bound) {
               // ---- spatial block `rec`: filter its 8 objects, then exact roots for the survivors
-              auto expand = [&](auto blk) {
+              auto expand = [&](auto blk, auto HS) {
+                constexpr int hs = decltype(HS)::value;
                 unsigned m8 = 0;
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j) {
                   double cx, cy, cz, f;
-                  spatial_center(blk + 8 * j, cx, cy, cz, f);
-                  m8 = push_bit(m8, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, blk[8 * j + 3]));
+                  spatial_center(blk + hs * j, HS, cx, cy, cz, f);
+                  m8 = push_bit(m8, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, blk[hs * j + 3]));
                 }
                 while (m8 != 0) {
                   const int bb = 31 - __builtin_clz(m8);
                   m8 &= ~(1u << bb);
                   const int j = 7 - bb;
                   double cx, cy, cz, f;
-                  spatial_center(blk + 8 * j, cx, cy, cz, f);
-                  exact_hit(cx, cy, cz, blk[8 * j + 3], (unsigned)p.spatial_base + rec * kBlock + (unsigned)j, f);
+                  spatial_center(blk + hs * j, HS, cx, cy, cz, f);
+                  exact_hit(cx, cy, cz, blk[hs * j + 3], (unsigned)p.spatial_base + rec * kBlock + (unsigned)j, f);
                 }
               };
               st_cand += kBlock;
-              if (staged) expand(shot_lds + (size_t)rec * (8 * kBlock));   // ds_read
-              else expand((gdptr)(uintptr_t)p.shot + (size_t)rec * (8 * kBlock));  // global_load
+              using S8 = std::integral_constant<int, 8>;
+              using S4 = std::integral_constant<int, 4>;
+              if (p.shot_stride == 8) {
+                if (staged) expand(shot_lds + (size_t)rec * (8 * kBlock), S8{});            // ds_read
+                else expand((gdptr)(uintptr_t)p.shot + (size_t)rec * (8 * kBlock), S8{});  // global_load
+              } else {
+                if (staged) expand(shot_lds + (size_t)rec * (4 * kBlock), S4{});
+                else expand((gdptr)(uintptr_t)p.shot + (size_t)rec * (4 * kBlock), S4{});
+              }
             } else {
               st_cand += 1;
               const double* c = p.cold + (size_t)rec * 16;

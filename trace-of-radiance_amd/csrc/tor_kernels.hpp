@@ -32,6 +32,7 @@ struct KParams {
   const double* cold;
   const double* bnd;   // TOR_ACCEL_BLOCKS: 8 float64 per block {lo xyz, hi xyz, 0, 0} (segment kind 3), else null
   const double* shot;  // TOR_ACCEL_BLOCKS: 8 float64 per spatial slot {c0 xyz, r^2, dc xyz, time-group id | -1}
+  int shot_stride;       // float64 per compact record: 8, or 4 when no spatial object moves
   int shot_lds_doubles;  // > 0: copy that many float64 of shot into LDS per workgroup (fits next to the queues)
   const double* sgrp;  // TOR_ACCEL_BLOCKS: {time0, time1 - time0} per time group
   int spatial_base;    // first cold slot of the spatial blocks: block b owns cold[spatial_base + 8b .. +8)

@@ -239,7 +239,8 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
     double* c = &out.cold[16 * (out.spatial_base + k)];
     std::fill(c, c + 16, 0.0);
     if (!fill_cold(c, objs[i], i)) { out = HostAccel{}; return; }
-    // compact record the block expansion reads: {c0 xyz, r^2, dc xyz, time-group id (-1: static)}
+    // compact record the block expansion reads: {c0 xyz, r^2, dc xyz, time-group id (-1: static)};
+    // re-packed to {c0 xyz, r^2} below when no spatial object moves
     double* hrec = &out.hot[8 * k];
     hrec[0] = c[0]; hrec[1] = c[1]; hrec[2] = c[2]; hrec[3] = c[15];
     hrec[4] = c[3]; hrec[5] = c[4]; hrec[6] = c[5];
@@ -267,7 +268,17 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
   if (out.always.n_segs == 0) out.always.segs.clear();
   out.always.segs.insert(out.always.segs.end(), {3.0, 0.0, (double)n_bnd_p, 0.0, 0.0, 0.0, 0.0, 0.0});
   out.always.n_segs += 1;
-  if (out.groups.empty()) out.groups.assign(2, 1.0);
+  out.hot_stride = 8;
+  if (out.groups.empty()) {
+    out.groups.assign(2, 1.0);
+    // all static: 32-byte records (a 1600-object scene then fits LDS next to the queues)
+    const size_t slots = n_bnd_slots * kPad;
+    std::vector<double> packed(4 * slots + 8, 0.0);
+    for (size_t k = 0; k < slots; ++k)
+      for (int a = 0; a < 4; ++a) packed[4 * k + a] = out.hot[8 * k + a];
+    out.hot.swap(packed);
+    out.hot_stride = 4;
+  }
   out.available = true;
 }
 

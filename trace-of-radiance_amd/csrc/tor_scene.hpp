@@ -29,7 +29,9 @@ struct HostAccel {
   bool available = false;
   HostLayout always;            // + one segment of kind 3 (the bounds) appended to always.segs
   std::vector<double> cold;     // always.cold followed by the spatial objects' cold records
-  std::vector<double> hot;      // 8 float64 per spatial slot {c0 xyz, r^2, dc xyz, time-group id or -1}
+  std::vector<double> hot;      // hot_stride float64 per spatial slot: {c0 xyz, r^2, dc xyz, time-group id or -1},
+                                // or {c0 xyz, r^2} when none of the spatial objects moves
+  int hot_stride = 8;
   std::vector<double> groups;   // {time0, time1 - time0} per time group of the spatial objects
   size_t spatial_base = 0;      // first cold slot of the spatial objects (multiple of 8)
   size_t n_blocks = 0;
