@@ -324,3 +324,25 @@ def test_host_canvas_rate(tor):
     if os.path.isdir(out):
         with open(os.path.join(out, "host_canvas_rate.json"), "w") as f:
             json.dump({"workload": f"{w}x{h}x{spp}spp", "seconds": dt, "msamples_per_s_pcie_inclusive": rate}, f)
+
+
+def test_c_host_example_reproduces_reference_image(tor, golden_dir, tmp_path):
+    """examples/trace_of_radiance_main.cpp is the reference's main() (trace_of_radiance.nim:26-71) on the
+    bare C ABI -- no Python, no torch, the system HIP runtime.  Its PPM must be the reference's image."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler on this box")
+    exe = str(tmp_path / "trace_of_radiance")
+    libdir = os.path.dirname(tor.LIB_PATH)
+    subprocess.run(["g++", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "trace_of_radiance_main.cpp"),
+                    "-L", libdir, "-ltor_mi355x", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                   check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    tok = r.stdout.split()
+    assert tok[0] == b"P3" and (int(tok[1]), int(tok[2]), int(tok[3])) == (384, 216, 255)
+    rgb = np.array(tok[4:], dtype=np.int64).reshape(216, 384, 3)
+    g = np.array(Image.open(os.path.join(golden_dir, "book2_motion_blur.png")).convert("RGB")).astype(np.int64)
+    assert int((rgb != g).sum()) <= 25 and int(np.abs(rgb - g).max()) <= 8
