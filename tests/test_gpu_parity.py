@@ -346,3 +346,58 @@ def test_c_host_example_reproduces_reference_image(tor, golden_dir, tmp_path):
     rgb = np.array(tok[4:], dtype=np.int64).reshape(216, 384, 3)
     g = np.array(Image.open(os.path.join(golden_dir, "book2_motion_blur.png")).convert("RGB")).astype(np.int64)
     assert int((rgb != g).sum()) <= 25 and int(np.abs(rgb - g).max()) <= 8
+
+
+def _random_records(rng, n, spread, with_big):
+    recs = []
+    if with_big:
+        recs.append([0, 0, -500, 0, 0, -500, 0, 0, 1, 500, 0, .5, .5, .5, 0, 0])
+    groups = [(0.0, 1.0), (-0.5, 0.5), (0.25, 2.0), (1.0, 0.0)]          # the last one runs backwards
+    while len(recs) < n:
+        x, y, z = rng.uniform(-spread, spread), rng.uniform(0.0, 0.3 * spread), rng.uniform(-spread, spread)
+        r = float(rng.choice([0.15, 0.2, 0.3, 0.45])) * (1 if rng.random() > 0.05 else -1)
+        mat = int(rng.integers(0, 3))
+        alb = rng.uniform(0.1, 0.95, 3)
+        fuzz, ri = rng.uniform(0, 0.6), rng.uniform(1.2, 1.8)
+        k = rng.random()
+        if k < 0.4:
+            recs.append([0, x, y, z, x, y, z, 0, 1, r, mat, *alb, fuzz, ri])
+        else:
+            t0, t1 = groups[int(rng.integers(0, len(groups)))]
+            d = rng.uniform(-0.6, 0.6, 3) if k < 0.8 else np.array([0.0, rng.uniform(0, 0.7), 0.0])
+            recs.append([1, x, y, z, x + d[0], y + d[1], z + d[2], t0, t1, r, mat, *alb, fuzz, ri])
+    if with_big:
+        recs.append([0, 1, 2.5, -1, 1, 2.5, -1, 0, 1, 2.5, 2, 0, 0, 0, 0, 1.5])
+    return np.asarray(recs, dtype=np.float64)
+
+
+def test_block_culling_randomised_scenes(tor, oracle):
+    """Property test for TOR_ACCEL_BLOCKS: on random scenes (64..420 objects, static / y-only / general
+    movers in four time groups incl. time1 < time0, hollow spheres, optional huge objects), cameras
+    outside and INSIDE the object cloud, and shutters that reach outside every [time0, time1], the
+    culled render is bit-identical to the brute-force render; one configuration per scene is also
+    checked against the oracle."""
+    rng = np.random.default_rng(20260928)
+    for trial in range(14):
+        n = int(rng.integers(64, 420))
+        spread = float(rng.choice([3.0, 6.0, 12.0]))
+        recs = _random_records(rng, n, spread, with_big=bool(trial % 2))
+        scene = tor.Scene.from_records(recs)
+        inside = trial % 3 == 0
+        look_from = tuple(rng.uniform(-0.5, 0.5, 3) * spread + (0, 0.2 * spread, 0)) if inside else (spread * 1.8, spread * 0.7, spread * 1.1)
+        shutter = [(0.0, 1.0), (-1.0, 3.0), (0.5, 0.5), (2.0, 1.0)][trial % 4]
+        ck = dict(look_from=look_from, look_at=(0.0, 0.1 * spread, 0.0), vertical_field_of_view=float(rng.uniform(20, 70)),
+                  aperture=float(rng.uniform(0, 0.3)), focus_distance=float(rng.uniform(1, 2) * spread),
+                  shutter_open=shutter[0], shutter_close=shutter[1])
+        cam = tor.camera(**ck)
+        h, w, spp = 20, 34, 6
+        seeding = trial % 2
+        base = _render(tor, scene, cam, h, w, spp, 12, seeding=seeding)
+        acc = _render(tor, scene, cam, h, w, spp, 12, seeding=seeding, accel=tor.ACCEL_BLOCKS)
+        assert np.array_equal(acc.pixels, base.pixels), f"trial {trial}: culling changed {(acc.pixels != base.pixels).sum()} values"
+        ocam = oracle.camera(look_from=ck["look_from"], look_at=ck["look_at"], vfov=ck["vertical_field_of_view"],
+                             aperture=ck["aperture"], focus_dist=ck["focus_distance"], shutter_open=shutter[0],
+                             shutter_close=shutter[1])
+        assert np.array_equal(cam.as_array(), ocam)
+        want = oracle.render(h, w, spp, ocam, recs, max_depth=12, seeding=seeding, math=1, arith=0, accum=seeding).pixels
+        _assert_parity(base.pixels, want)
