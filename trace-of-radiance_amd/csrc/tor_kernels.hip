@@ -1,36 +1,46 @@
 // tor_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the trace-of-radiance integrator.
 //
-//   integrate_kernel<SEEDING, ARITH>
+//   integrate_kernel<SEEDING, ARITH, WAVES_PER_SIMD>
 //     render.nim:49-68 (render) + render.nim:21-47 (radiance) + hittables_lists.nim:48-55
 //     (closest hit) + spheres.nim:28-49 / moving_spheres.nim:46-67 + materials.nim:21-96.
 //
-//     Persistent waves with path regeneration: every lane owns one path at a time; a lane
-//     whose path ended (sky, absorbed, depth exhausted) is refilled at the top of the next
-//     bounce iteration with the next work item (wave ballot + prefix count over a wave-uniform
-//     range that is itself pulled in chunks from one global counter).  So the hot loop --
-//     the brute-force ray x all-objects test, >95 % of the float64 work -- always runs with
-//     full waves, whatever the mix of path lengths (1..max_depth).
-//       TOR_SEED_PIXEL : work item = pixel; the lane runs that pixel's spp samples in order on
-//                        the pixel's own stream and sums them in sample order (bit-faithful
-//                        to render.nim:59-67).
-//       TOR_SEED_SAMPLE: work item = pixel-sample; per-sample stream; radiance is rounded to
-//                        2^-36 and accumulated with float64 atomics -- every partial sum is
-//                        exact, so the pixel is independent of scheduling.
+//     Persistent waves with path regeneration: every lane owns one path at a time; a lane whose
+//     path ended (sky, absorbed, depth exhausted) is refilled at the top of the next bounce
+//     iteration with the next work item (wave ballot + prefix count over a wave-uniform range that
+//     is itself pulled from one global counter).  The hot loop -- the brute-force ray x all-objects
+//     test, ~87 % of the VALU instructions -- therefore always runs with full waves, whatever the
+//     mix of path lengths (1..max_depth).
+//       SEEDING 0 (TOR_SEED_PIXEL) : work item = a tile of 64 pixels; a lane runs its pixel's spp
+//                        samples in order on the pixel's own stream and sums them in sample order
+//                        (bit-faithful to render.nim:59-67).  Tiles come most-expensive-first when
+//                        the host ran the probe (SEEDING 2) and tile_order_kernel.
+//       SEEDING 1 (TOR_SEED_SAMPLE): work item = pixel-sample, guided chunks; per-sample stream;
+//                        radiance is rounded to 2^-36 and accumulated in a per-wave LDS cache, then
+//                        with float64 atomics -- every partial sum is exact, so the pixel does not
+//                        depend on the schedule.
+//       SEEDING 2 (probe)          : SEEDING 1 streams, 2 spp; only counts closest-hit queries per
+//                        tile (input of the SEED_PIXEL tile schedule); never touches the canvas.
 //
-//     Objects are wave-uniform inside the hot loop, so their records come through the scalar
-//     data path (s_load into SGPRs, constant bus operand of the VALU op): no VGPRs, no LDS
-//     bandwidth, no per-lane addresses.  Per test the lanes compute only the discriminant of
-//     the quadratic (17 float64 ops for a static sphere) and a sign-bit filter; the square
-//     root and the two divisions of the reference's `hit` are deferred to a short per-lane
-//     pass over the few objects whose discriminant was positive (queued in LDS).  Closest
-//     hit is order independent (hittables_lists.nim:48-55: strict `<`, ties keep the lowest
-//     index) so the deferred pass reproduces the sequential scan exactly.
+//     Objects are wave-uniform inside the hot loop, so their records come through the scalar data
+//     path (s_load into SGPRs, constant-bus operand of the VALU op): no VGPRs, no LDS bandwidth,
+//     no per-lane addresses.  Per test the lanes compute only the discriminant of the quadratic
+//     (17 / 19 / 23 float64 ops for a static / y-only moving / moving sphere) and a sign-bit
+//     filter (one v_bitop3 + one v_alignbit into an 8-object mask); the square root and the two
+//     divisions of the reference's `hit` are deferred to a short per-lane pass over the few
+//     objects whose discriminant was positive (masks queued in LDS).  Closest hit is order
+//     independent (hittables_lists.nim:48-55: strict `<`, ties keep the lowest index) so the
+//     deferred pass reproduces the sequential scan exactly.
 //
-//   finalize_kernel   canvas.nim:47-54 (draw): pow(sum * 1/spp, 1/gamma)
-//   quantize_kernel   io/ppm.nim:15-16
+//     TOR_ACCEL_BLOCKS (segment kind 3): the wave-uniform loop tests conservative boxes around
+//     spatial blocks of 8 objects instead of the objects; the deferred pass expands, per lane, only
+//     the blocks whose box the ray can touch (compact records, staged in LDS when they fit).
+//
+//   tile_order_kernel  counting sort of the SEED_PIXEL tiles by probed cost (LPT schedule)
+//   finalize_kernel    canvas.nim:47-54 (draw): pow(sum * 1/spp, 1/gamma)
+//   quantize_kernel    io/ppm.nim:15-16
 //
 // float64 throughout, no FMA contraction (-ffp-contract=off); TOR_ARITH_FUSED uses explicit
-// fma() in the discriminant only.
+// fma() in the discriminant and the moving-sphere centre only.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
