@@ -91,8 +91,11 @@ struct TorContext {
   // work
   DeviceBuffer counters;  // [0] work counter, [1..4] stats
   DeviceBuffer tile_cost, tile_order;  // SEED_PIXEL cost-ordered schedule
-  DeviceBuffer wave_log;  // debug: 4 x u64 per wave (only with stats enabled)
+  DeviceBuffer wave_log;  // debug: 8 x u64 per wave (only with stats enabled)
   DeviceBuffer cam_ring;  // 64 x TorCamera: one slot per in-flight launch (async-safe)
+  // host-side staging of the per-launch data: it must outlive the asynchronous copies
+  TorCamera cam_host[64];
+  std::vector<double> bnd_host[64];
   DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
   bool collect_stats = false;
   static constexpr int kEventRing = 64;
@@ -135,12 +138,6 @@ bool valid_options(const TorOptions* opt, TorOptions& o) {
   if (o.row_tile < 1) o.row_tile = 1;
   if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
   return true;
-}
-
-inline double i64_as_double(int64_t v) {
-  double d;
-  std::memcpy(&d, &v, 8);
-  return d;
 }
 
 }  // namespace
@@ -229,6 +226,9 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
     return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: bad HittableList");
   if (world.len > (int64_t)1 << 24) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: too many objects");
   HIP_TRY(hipSetDevice(ctx->device));
+  // the scene buffers are about to be overwritten / reallocated: no launch may still be reading them
+  HIP_TRY(hipDeviceSynchronize());
+  ctx->scene_ready = false;
   const int64_t n = world.len;
   std::vector<int64_t> ids((size_t)n);
   for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = i;
@@ -323,7 +323,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.sgrp = nullptr;
   p.shot_lds_doubles = 0;
   p.shot_stride = 8;
-  std::vector<double> bnd_host;
+  const int slot = (int)(ctx->launches % TorContext::kEventRing);
+  // a ring slot (events, camera, bounds) is reused every 64 launches: its previous launch must be done
+  if (ctx->launches >= TorContext::kEventRing) HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
+  std::vector<double>& bnd_host = ctx->bnd_host[slot];
   bool use_accel = false;
   int stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
   if (o.accel == TOR_ACCEL_BLOCKS && ctx->accel.available) {
@@ -398,11 +401,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     ctx->last_n_waves = (int64_t)p.n_waves;
   }
 
-  const int slot = (int)(ctx->launches % TorContext::kEventRing);
-  // the camera travels in its own small device slot (one per in-flight launch; a slot is reused
-  // only after 64 further launches on this context)
+  // the camera travels in its own small device slot (one per in-flight launch)
+  ctx->cam_host[slot] = *cam;
   p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
-  HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, cam, sizeof(TorCamera), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, &ctx->cam_host[slot], sizeof(TorCamera), hipMemcpyHostToDevice, stream));
   if (use_accel) {
     p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);
     HIP_TRY(hipMemcpyAsync((void*)p.bnd, bnd_host.data(), bnd_host.size() * 8, hipMemcpyHostToDevice, stream));
@@ -582,21 +584,24 @@ int tor_selftest_math_device(int32_t op, const double* x, const double* y, doubl
   if (e != hipSuccess || count <= 0) return fail(TOR_ERR_NO_DEVICE, "no HIP device available");
   if (device >= 0) HIP_TRY(hipSetDevice(device));
   const size_t bytes = (size_t)n * 8;
-  double *dx = nullptr, *dy = nullptr, *d0 = nullptr, *d1 = nullptr;
-  HIP_TRY(hipMalloc((void**)&dx, bytes + 8));
-  HIP_TRY(hipMalloc((void**)&dy, bytes + 8));
-  HIP_TRY(hipMalloc((void**)&d0, bytes + 8));
-  HIP_TRY(hipMalloc((void**)&d1, bytes + 8));
-  HIP_TRY(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
-  if (y) HIP_TRY(hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
-  else HIP_TRY(hipMemset(dy, 0, bytes));
-  HIP_TRY(hipMemset(d0, 0, bytes));
-  HIP_TRY(hipMemset(d1, 0, bytes));
-  HIP_TRY(tor::launch_selftest(op, dx, dy, d0, d1, n, nullptr));
+  DeviceBuffer bx, by, b0, b1;  // released on every path
+  struct Release {
+    DeviceBuffer *a, *b, *c, *d;
+    ~Release() { a->release(); b->release(); c->release(); d->release(); }
+  } release{&bx, &by, &b0, &b1};
+  HIP_TRY(bx.ensure(bytes + 8));
+  HIP_TRY(by.ensure(bytes + 8));
+  HIP_TRY(b0.ensure(bytes + 8));
+  HIP_TRY(b1.ensure(bytes + 8));
+  HIP_TRY(hipMemcpy(bx.ptr, x, bytes, hipMemcpyHostToDevice));
+  if (y) HIP_TRY(hipMemcpy(by.ptr, y, bytes, hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemset(by.ptr, 0, bytes));
+  HIP_TRY(hipMemset(b0.ptr, 0, bytes));
+  HIP_TRY(hipMemset(b1.ptr, 0, bytes));
+  HIP_TRY(tor::launch_selftest(op, (const double*)bx.ptr, (const double*)by.ptr, (double*)b0.ptr, (double*)b1.ptr, n, nullptr));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost));
-  if (out1) HIP_TRY(hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost));
-  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(d0); (void)hipFree(d1);
+  HIP_TRY(hipMemcpy(out0, b0.ptr, bytes, hipMemcpyDeviceToHost));
+  if (out1) HIP_TRY(hipMemcpy(out1, b1.ptr, bytes, hipMemcpyDeviceToHost));
   return TOR_OK;
 }
 
