@@ -193,6 +193,22 @@ TOR_API int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nro
 TOR_API int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, int64_t n_values,
                                      uint8_t* d_rgb8, void* hip_stream);
 
+/* Video output stage of the animation driver (trace_of_radiance_animation.nim:186-196), one fused
+ * device kernel per frame: Canvas -> RGB8 (io/rgb.nim:17-31, top scanline first) -> BT.601 Y'CbCr
+ * 4:2:0 (io/color_conversions.nim:180-252) -> one I_PCM slice (io/h264.nim:249-259).
+ *   tor_h264_stream_header : SPS (h264.nim:90-142) + PPS (h264.nim:37), written once per stream
+ *   tor_h264_frame_bytes   : size of one frame's slice NAL unit (width, height multiples of 16)
+ *   tor_encode_frame_device: d_pixels = finished canvas (nrows*ncols*3 float64, row 0 = bottom);
+ *                            d_slice receives tor_h264_frame_bytes() bytes; d_y/d_cb/d_cr (nullable)
+ *                            receive the planes (H264Encoder.getFrameBuffers, h264.nim:206-224).
+ * Concatenating header + slices gives the Annex-B .264 file of main_animation_mp4; MP4 muxing
+ * (io/mp4.nim -> vendored minimp4) stays on the host and is out of scope. */
+TOR_API int tor_h264_stream_header(int32_t width, int32_t height, uint8_t* out, int32_t cap);
+TOR_API int64_t tor_h264_frame_bytes(int32_t width, int32_t height);
+TOR_API int tor_encode_frame_device(TorContext* ctx, const double* d_pixels, int32_t nrows, int32_t ncols,
+                                    uint8_t* d_slice, uint8_t* d_y, uint8_t* d_cb, uint8_t* d_cr,
+                                    void* hip_stream);
+
 /* Timing of the last tor_render_device call on this context, measured with HIP events
  * recorded on the launch stream around the integrator kernel only (ms); blocks until the
  * kernel has finished.  samples_out (nullable) = pixel-samples that launch traced. */

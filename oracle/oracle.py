@@ -96,6 +96,13 @@ def lib(variant: str | None = None):
     L.oracle_quantize36.restype = C.c_double
     L.oracle_quantize_ppm.argtypes = [dp, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
     L.oracle_num_threads.restype = C.c_int
+    u8p = C.POINTER(C.c_uint8)
+    L.oracle_to_rgb_raw.argtypes = [dp, C.c_int32, C.c_int32, u8p]
+    L.oracle_rgb_to_ycbcr420.argtypes = [C.c_int32, C.c_int32, u8p, u8p, u8p, u8p]
+    L.oracle_h264_stream_header.argtypes = [C.c_int32, C.c_int32, u8p]
+    L.oracle_h264_stream_header.restype = C.c_int
+    L.oracle_h264_flush_frame.argtypes = [C.c_int32, C.c_int32, u8p, u8p, u8p, u8p]
+    L.oracle_h264_flush_frame.restype = C.c_int64
     L.oracle_animation_create.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float]
     L.oracle_animation_create.restype = C.c_void_p
     L.oracle_animation_destroy.argtypes = [C.c_void_p]
@@ -198,3 +205,26 @@ def animation_scenes(height, width, dt=0.005, t_min=0.0, t_max=2.0, skip=6, seed
             k += 1
     finally:
         L.oracle_animation_destroy(h)
+
+
+def encode_frame(pixels: np.ndarray):
+    """io/rgb.nim + io/color_conversions.nim + io/h264.nim on one canvas -> (rgb, Y, Cb, Cr, slice bytes)."""
+    L = lib()
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    nrows, ncols, _ = pixels.shape
+    p = np.ascontiguousarray(pixels, dtype=np.float64)
+    rgb = np.zeros((nrows, ncols, 3), dtype=np.uint8)
+    L.oracle_to_rgb_raw(_dp(p), nrows, ncols, u8(rgb))
+    Y = np.zeros((nrows, ncols), dtype=np.uint8)
+    Cb = np.zeros((nrows // 2, ncols // 2), dtype=np.uint8)
+    Cr = np.zeros((nrows // 2, ncols // 2), dtype=np.uint8)
+    L.oracle_rgb_to_ycbcr420(ncols, nrows, u8(rgb), u8(Y), u8(Cb), u8(Cr))
+    out = np.zeros(nrows * ncols * 2 + 64, dtype=np.uint8)
+    n = L.oracle_h264_flush_frame(ncols, nrows, u8(Y), u8(Cb), u8(Cr), u8(out))
+    return rgb, Y, Cb, Cr, out[:n].tobytes()
+
+
+def h264_stream_header(width: int, height: int) -> bytes:
+    buf = np.zeros(64, dtype=np.uint8)
+    n = lib().oracle_h264_stream_header(width, height, buf.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return buf[:n].tobytes()

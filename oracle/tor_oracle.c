@@ -894,3 +894,117 @@ EXPORT int oracle_animation_next(void* h, int32_t skip, double cam24[24], double
   for (int32_t i = 0; i < skip; ++i) o_anim_step(a);
   return 1;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Video output stage -- io/rgb.nim, io/color_conversions.nim, io/h264.nim     */
+/* ------------------------------------------------------------------------- */
+/* PARITY UNPINNED: the reference holds no encoded frame, and color_conversions.nim's own self-test
+ * needs yuv_rgb.c which is not in the tree (:329-331).  Restated from the sources; the tests add
+ * known answers of the BT.601 limited-range matrix (white -> 235/128/128, black -> 16/128/128). */
+
+/* io/rgb.nim:17-31 -> out[(i*ncols + j)*3 + c], i = 0 is the TOP scanline.  rgb.nim:29-31 reads
+ * canvas[nrows - i, j] (row nrows for i = 0: out of bounds); the intended flip nrows-1-i is used. */
+EXPORT void oracle_to_rgb_raw(const double* pixels, int32_t nrows, int32_t ncols, uint8_t* out) {
+  for (int32_t i = nrows - 1; i >= 0; --i)
+    for (int32_t j = 0; j < ncols; ++j)
+      for (int ch = 0; ch < 3; ++ch) {
+        double c = pixels[((size_t)(nrows - 1 - i) * ncols + j) * 3 + ch];
+        double cl = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);
+        out[((size_t)i * ncols + j) * 3 + ch] = (uint8_t)(256 * cl);
+      }
+}
+
+static uint8_t to_fixed_u8(double x, int precision) { return (uint8_t)(x * (double)(1 << precision) + 0.5); } /* :107-108 */
+
+/* io/color_conversions.nim:180-252 with the BT601 coefficients of :110-120,176-178 */
+EXPORT void oracle_rgb_to_ycbcr420(int32_t width, int32_t height, const uint8_t* rgb, uint8_t* Y, uint8_t* U, uint8_t* V) {
+  const double kr_f = 0.299, kb_f = 0.114, ymin = 16.0, ymax = 235.0, cbcr = 240.0 - 16.0;
+  const uint8_t kr = to_fixed_u8(kr_f, 8), kb = to_fixed_u8(kb_f, 8);
+  const uint8_t kg = (uint8_t)(256 - kr - kb);
+  const uint8_t fb = to_fixed_u8((cbcr / 255.0) / (2.0 * (1.0 - kb_f)), 8);
+  const uint8_t fr = to_fixed_u8((cbcr / 255.0) / (2.0 * (1.0 - kr_f)), 8);
+  const uint8_t y_scale = to_fixed_u8((ymax - ymin) / 255.0, 7);
+  const uint8_t y_min = (uint8_t)ymin;
+  const int32_t cstride = (width + 1) / 2;
+  for (int32_t ii = 0; ii < height; ii += 2)
+    for (int32_t jj = 0; jj < width; jj += 2) {
+      int16_t tU = 0, tV = 0;
+      for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj) {
+          const uint8_t* p = rgb + ((size_t)(ii + di) * width + (jj + dj)) * 3;
+          uint16_t tY = (uint16_t)(((uint16_t)kr * p[0] + (uint16_t)kg * p[1] + (uint16_t)kb * p[2]) >> 8);
+          tU = (int16_t)(tU + ((int16_t)p[2] - (int16_t)tY));
+          tV = (int16_t)(tV + ((int16_t)p[0] - (int16_t)tY));
+          Y[(size_t)(ii + di) * width + (jj + dj)] = (uint8_t)((uint8_t)(((uint16_t)(tY * y_scale)) >> 7) + y_min);
+        }
+      U[(size_t)(ii >> 1) * cstride + (jj >> 1)] = (uint8_t)((int16_t)(((int16_t)((tU >> 2) * (int16_t)fb)) >> 8) + 128);
+      V[(size_t)(ii >> 1) * cstride + (jj >> 1)] = (uint8_t)((int16_t)(((int16_t)((tV >> 2) * (int16_t)fr)) >> 8) + 128);
+    }
+}
+
+/* io/h264.nim: BitBuffer (:51-81) */
+typedef struct { int shift; uint32_t cache; uint8_t* buf; int cursor; } OBits;
+static void ob_store(OBits* bb) { uint32_t c = bb->cache; bb->buf[bb->cursor] = (uint8_t)(c >> 24); bb->buf[bb->cursor + 1] = (uint8_t)(c >> 16); bb->buf[bb->cursor + 2] = (uint8_t)(c >> 8); bb->buf[bb->cursor + 3] = (uint8_t)c; }
+static void ob_put(OBits* bb, int n, uint32_t val) {
+  bb->shift -= n;
+  if (bb->shift < 0) {
+    bb->cache |= (val >> -bb->shift);
+    ob_store(bb);
+    bb->cursor += 4;
+    bb->shift += 32;
+    bb->cache = 0;
+  }
+  if (bb->shift < 32) bb->cache |= (val << bb->shift);
+}
+static void ob_golomb(OBits* bb, uint32_t val) {
+  int size = 1;
+  uint32_t t = val + 1;
+  while ((t >>= 1) != 0) ++size;
+  ob_put(bb, 2 * size - 1, val + 1);
+}
+
+/* H264Encoder.init (:169-176): SPS (:90-142) then the constant PPS (:37). Returns the byte count. */
+EXPORT int oracle_h264_stream_header(int32_t width, int32_t height, uint8_t* out) {
+  uint8_t sps[64];
+  memset(sps, 0, sizeof sps);
+  OBits bb = { 0, 0, sps, 0 };
+  sps[0] = 0; sps[1] = 0; sps[2] = 0; sps[3] = 1;
+  bb.shift = 32; bb.cursor = 4;
+  ob_put(&bb, 1, 0); ob_put(&bb, 2, 3); ob_put(&bb, 5, 7);
+  ob_put(&bb, 8, 66);
+  ob_put(&bb, 1, 0); ob_put(&bb, 1, 0); ob_put(&bb, 1, 0); ob_put(&bb, 1, 0);
+  ob_put(&bb, 4, 0);
+  ob_put(&bb, 8, 10);
+  ob_golomb(&bb, 0); ob_golomb(&bb, 0); ob_golomb(&bb, 0); ob_golomb(&bb, 0);
+  ob_golomb(&bb, 0);
+  ob_put(&bb, 1, 0);
+  ob_golomb(&bb, (uint32_t)(((width + 15) >> 4) - 1));
+  ob_golomb(&bb, (uint32_t)(((height + 15) >> 4) - 1));
+  ob_put(&bb, 1, 1); ob_put(&bb, 1, 0); ob_put(&bb, 1, 0);
+  ob_put(&bb, 1, 0); ob_put(&bb, 1, 1);
+  ob_store(&bb); bb.cursor += 4;                 /* flush */
+  int n = bb.cursor - bb.shift / 8;
+  memcpy(out, sps, (size_t)n);
+  static const uint8_t PPS[8] = { 0x00, 0x00, 0x00, 0x01, 0x68, 0xce, 0x38, 0x80 };
+  memcpy(out + n, PPS, 8);
+  return n + 8;
+}
+
+/* flushFrame (:249-259) + encodeMacroblock (:189-202). Returns the byte count. */
+EXPORT int64_t oracle_h264_flush_frame(int32_t width, int32_t height, const uint8_t* Y, const uint8_t* Cb, const uint8_t* Cr, uint8_t* out) {
+  static const uint8_t SliceHeader[9] = { 0x00, 0x00, 0x00, 0x01, 0x05, 0x88, 0x84, 0x21, 0xa0 };
+  int64_t k = 0;
+  memcpy(out, SliceHeader, 9); k = 9;
+  for (int i = 0; i < height / 16; ++i)
+    for (int j = 0; j < width / 16; ++j) {
+      if (!(i == 0 && j == 0)) { out[k++] = 0x0d; out[k++] = 0x00; }
+      for (int x = i * 16; x < (i + 1) * 16; ++x)
+        for (int y = j * 16; y < (j + 1) * 16; ++y) out[k++] = Y[(size_t)x * width + y];
+      for (int x = i * 8; x < (i + 1) * 8; ++x)
+        for (int y = j * 8; y < (j + 1) * 8; ++y) out[k++] = Cb[(size_t)x * (width >> 1) + y];
+      for (int x = i * 8; x < (i + 1) * 8; ++x)
+        for (int y = j * 8; y < (j + 1) * 8; ++y) out[k++] = Cr[(size_t)x * (width >> 1) + y];
+    }
+  out[k++] = 0x80;
+  return k;
+}

@@ -1,0 +1,85 @@
+"""the animation driver's per-frame output stage -- Canvas -> RGB8 (io/rgb.nim) ->
+BT.601 Y'CbCr 4:2:0 (io/color_conversions.nim) -> I_PCM H.264 slice (io/h264.nim).  The product fuses
+it into one device kernel; the oracle restates the three reference routines one by one.  PARITY
+UNPINNED against the reference (no encoded frame in the tree; its own self-test needs an absent
+yuv_rgb.c), so known answers of the BT.601 limited-range matrix are checked as well."""
+import numpy as np
+import pytest
+
+
+def _parse_slice(b, width, height):
+    """Minimal I_PCM slice reader: returns (Y, Cb, Cr) planes recovered from the byte stream."""
+    assert b[:9] == bytes([0, 0, 0, 1, 0x05, 0x88, 0x84, 0x21, 0xa0])
+    Y = np.zeros((height, width), np.uint8); Cb = np.zeros((height // 2, width // 2), np.uint8); Cr = np.zeros_like(Cb)
+    k = 9
+    for i in range(height // 16):
+        for j in range(width // 16):
+            if not (i == 0 and j == 0):
+                assert b[k:k + 2] == b"\x0d\x00"
+                k += 2
+            Y[i * 16:(i + 1) * 16, j * 16:(j + 1) * 16] = np.frombuffer(b[k:k + 256], np.uint8).reshape(16, 16); k += 256
+            Cb[i * 8:(i + 1) * 8, j * 8:(j + 1) * 8] = np.frombuffer(b[k:k + 64], np.uint8).reshape(8, 8); k += 64
+            Cr[i * 8:(i + 1) * 8, j * 8:(j + 1) * 8] = np.frombuffer(b[k:k + 64], np.uint8).reshape(8, 8); k += 64
+    assert b[k] == 0x80 and k + 1 == len(b)
+    return Y, Cb, Cr
+
+
+def test_oracle_video_stage_known_answers(oracle):
+    h, w = 32, 48
+    for colour, want in (((1.0, 1.0, 1.0), (235, 128, 128)), ((0.0, 0.0, 0.0), (16, 128, 128)),
+                         ((1.0, 0.0, 0.0), (81, 90, 239)), ((0.0, 0.0, 1.0), (40, 240, 110))):   # BT.601 limited range
+        px = np.empty((h, w, 3)); px[:] = colour
+        rgb, Y, Cb, Cr, sl = oracle.encode_frame(px)
+        assert abs(int(Y[0, 0]) - want[0]) <= 1 and abs(int(Cb[0, 0]) - want[1]) <= 2 and abs(int(Cr[0, 0]) - want[2]) <= 2, (colour, Y[0, 0], Cb[0, 0], Cr[0, 0])
+        assert len(sl) == (h // 16) * (w // 16) * 386 + 8
+        y2, cb2, cr2 = _parse_slice(sl, w, h)
+        assert np.array_equal(y2, Y) and np.array_equal(cb2, Cb) and np.array_equal(cr2, Cr)
+    # vertical flip: canvas row 0 is the bottom scanline, video row 0 the top one
+    px = np.zeros((32, 32, 3)); px[31] = 1.0
+    rgb, Y, _, _, _ = oracle.encode_frame(px)
+    assert rgb[0].min() == 255 and rgb[1:].max() == 0 and Y[0, 0] == 235 and Y[31, 0] == 16
+
+
+def test_h264_stream_header_matches_oracle(tor, oracle):
+    for w, h in ((256, 144), (384, 216), (576, 324), (1920, 1088), (16, 16)):
+        hdr = tor.h264_stream_header(w, h)
+        assert hdr == oracle.h264_stream_header(w, h)
+        assert hdr[:5] == b"\x00\x00\x00\x01\x67" and hdr[5] == 66 and hdr[7] == 10   # SPS NAL, baseline, level 1
+        assert hdr[-8:] == bytes([0, 0, 0, 1, 0x68, 0xce, 0x38, 0x80])
+    assert tor.h264_frame_bytes(256, 144) == 16 * 9 * 386 + 8
+    with pytest.raises(tor.TorError):
+        tor.h264_frame_bytes(384, 216)       # 216 is not a multiple of 16 (h264.nim:178 TODO)
+
+
+@pytest.mark.gpu
+def test_device_video_stage_is_byte_exact(tor, oracle):
+    import torch
+    ctx = tor.Context()
+    rng = np.random.default_rng(9)
+    for h, w in ((16, 16), (144, 256), (1088, 1920)):
+        px = rng.uniform(-0.1, 1.1, (h, w, 3))
+        px[0, :8] = 0.999; px[1, :8] = 1.0; px[2, :8] = 0.0; px[3, :8] = np.nextafter(0.999, 0)
+        d = torch.from_numpy(px).cuda()
+        n = tor.h264_frame_bytes(w, h)
+        out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        Y = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+        Cb = torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda"); Cr = torch.zeros_like(Cb)
+        ctx.encode_frame_device(d.data_ptr(), h, w, out.data_ptr(), Y.data_ptr(), Cb.data_ptr(), Cr.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        _, oY, oCb, oCr, osl = oracle.encode_frame(px)
+        assert np.array_equal(Y.cpu().numpy(), oY) and np.array_equal(Cb.cpu().numpy(), oCb) and np.array_equal(Cr.cpu().numpy(), oCr)
+        assert out.cpu().numpy().tobytes() == osl
+    # a rendered animation frame through the whole path: render -> encode on the device
+    cam, scene, _ = next(iter(tor.Animation(144, 256, 0.005, 0.2, 2.0).scenes(6)))
+    ctx.upload(scene.list())
+    frame = torch.empty((144, 256, 3), dtype=torch.float64, device="cuda")
+    ctx.render_device(cam, 144, 256, 4, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE), frame.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    out = torch.zeros(tor.h264_frame_bytes(256, 144), dtype=torch.uint8, device="cuda")
+    ctx.encode_frame_device(frame.data_ptr(), 144, 256, out.data_ptr(), stream_ptr=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == oracle.encode_frame(frame.cpu().numpy())[4]
+    with pytest.raises(tor.TorError):
+        ctx.encode_frame_device(frame.data_ptr(), 100, 256, out.data_ptr())
+    ctx.close()

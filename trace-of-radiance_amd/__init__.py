@@ -122,7 +122,8 @@ EXPORTED_SYMBOLS = [
     "tor_scene_upload", "tor_shard_rows", "tor_render_device", "tor_quantize_rgb8_device",
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
-    "tor_animation_object_count", "tor_animation_next", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
+    "tor_encode_frame_device", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -189,6 +190,11 @@ def lib():
     L.tor_animation_object_count.restype = C.c_int64
     L.tor_animation_next.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Camera), C.POINTER(HittableVariant), C.c_int64,
                                      C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+    L.tor_h264_stream_header.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int32]
+    L.tor_h264_frame_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.tor_h264_frame_bytes.restype = C.c_int64
+    L.tor_encode_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -395,6 +401,22 @@ def export_ppm(canvas: Canvas, f) -> None:
         f.write(f"{r} {g} {b}\n")
 
 
+def h264_stream_header(width: int, height: int) -> bytes:
+    """SPS + PPS as H264Encoder.init writes them (io/h264.nim:90-142,37,174-176)."""
+    buf = (C.c_uint8 * 64)()
+    n = lib().tor_h264_stream_header(width, height, buf, 64)
+    if n < 0:
+        raise TorError(n, "tor_h264_stream_header failed")
+    return bytes(buf[:n])
+
+
+def h264_frame_bytes(width: int, height: int) -> int:
+    n = int(lib().tor_h264_frame_bytes(width, height))
+    if n < 0:
+        raise TorError(n, "width and height must be multiples of 16")
+    return n
+
+
 def shard_rows(nrows: int, row_tile: int, shard_index: int, shard_count: int) -> np.ndarray:
     buf = (C.c_int32 * max(nrows, 1))()
     n = lib().tor_shard_rows(nrows, row_tile, shard_index, shard_count, buf)
@@ -434,6 +456,13 @@ class Context:
     def quantize_rgb8_device(self, d_pixels_ptr: int, n_values: int, d_rgb8_ptr: int, stream_ptr: int = 0):
         _check(lib().tor_quantize_rgb8_device(self._h, C.c_void_p(d_pixels_ptr), n_values,
                                               C.c_void_p(d_rgb8_ptr), C.c_void_p(stream_ptr)))
+
+    def encode_frame_device(self, d_pixels_ptr: int, nrows: int, ncols: int, d_slice_ptr: int, d_y_ptr: int = 0,
+                            d_cb_ptr: int = 0, d_cr_ptr: int = 0, stream_ptr: int = 0):
+        """canvas -> RGB8 -> Y'CbCr 4:2:0 -> I_PCM slice bytes (io/rgb.nim, color_conversions.nim, h264.nim)."""
+        _check(lib().tor_encode_frame_device(self._h, C.c_void_p(d_pixels_ptr), nrows, ncols, C.c_void_p(d_slice_ptr),
+                                             C.c_void_p(d_y_ptr), C.c_void_p(d_cb_ptr), C.c_void_p(d_cr_ptr),
+                                             C.c_void_p(stream_ptr)))
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

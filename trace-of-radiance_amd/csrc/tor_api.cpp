@@ -455,6 +455,63 @@ int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, int64_t n_
   return TOR_OK;
 }
 
+// ---- video output stage (io/rgb.nim, io/color_conversions.nim, io/h264.nim) --------------------
+
+int64_t tor_h264_frame_bytes(int32_t width, int32_t height) {
+  if (width < 16 || height < 16 || (width & 15) || (height & 15)) return TOR_ERR_INVALID_ARGUMENT;
+  const int64_t n_mb = (int64_t)(width >> 4) * (height >> 4);
+  return n_mb * 386 + 8;  // slice header 9 + 384 per macroblock + 2 per macroblock after the first + stop byte
+}
+
+// initSPS (h264.nim:90-142) followed by the constant PPS (h264.nim:37), as H264Encoder.init writes
+// them (h264.nim:174-176).  Returns the number of bytes written or a negative status.
+int tor_h264_stream_header(int32_t width, int32_t height, uint8_t* out, int32_t cap) {
+  if (!out || width < 1 || height < 1) return TOR_ERR_INVALID_ARGUMENT;
+  std::vector<uint8_t> b = {0x00, 0x00, 0x00, 0x01};
+  unsigned acc = 0;
+  int nbits = 0;
+  auto put = [&](int n, unsigned v) {  // MSB first
+    for (int k = n - 1; k >= 0; --k) {
+      acc = (acc << 1) | ((v >> k) & 1u);
+      if (++nbits == 8) { b.push_back((uint8_t)acc); acc = 0; nbits = 0; }
+    }
+  };
+  auto ue = [&](unsigned v) {  // putGolomb, h264.nim:73-78
+    int size = 1;
+    unsigned t = v + 1;
+    while ((t >>= 1) != 0) ++size;
+    put(2 * size - 1, v + 1);
+  };
+  put(1, 0); put(2, 3); put(5, 7);        // forbidden_zero_bit, nal_ref_idc, nal_unit_type = SPS
+  put(8, 66);                             // baseline profile
+  put(1, 0); put(1, 0); put(1, 0); put(1, 0); put(4, 0);  // constraint flags, reserved
+  put(8, 10);                             // level_idc
+  ue(0); ue(0); ue(0); ue(0);             // sps id, log2_max_frame_num-4, poc type, log2_max_poc_lsb-4
+  ue(0); put(1, 0);                       // num_ref_frames, gaps_in_frame_num_value_allowed
+  ue((unsigned)(((width + 15) >> 4) - 1));
+  ue((unsigned)(((height + 15) >> 4) - 1));
+  put(1, 1); put(1, 0); put(1, 0);        // frame_mbs_only, direct_8x8_inference, frame_cropping (never set)
+  put(1, 0); put(1, 1);                   // vui_parameters_present, stop bit
+  if (nbits > 0) b.push_back((uint8_t)(acc << (8 - nbits)));
+  const uint8_t pps[8] = {0x00, 0x00, 0x00, 0x01, 0x68, 0xce, 0x38, 0x80};
+  b.insert(b.end(), pps, pps + 8);
+  if ((int)b.size() > cap) return TOR_ERR_INVALID_ARGUMENT;
+  std::memcpy(out, b.data(), b.size());
+  return (int)b.size();
+}
+
+int tor_encode_frame_device(TorContext* ctx, const double* d_pixels, int32_t nrows, int32_t ncols, uint8_t* d_slice,
+                            uint8_t* d_y, uint8_t* d_cb, uint8_t* d_cr, void* hip_stream) {
+  if (!ctx || !d_pixels || !d_slice) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_encode_frame_device: NULL argument");
+  // h264.nim:178 "TODO cropping for non-multiple of 16": the reference silently drops the partial
+  // macroblock rows/columns (flushFrame loops over `div 16`); this ABI rejects such frames instead.
+  if (tor_h264_frame_bytes(ncols, nrows) < 0)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_encode_frame_device: width and height must be multiples of 16");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(tor::launch_encode_ipcm(d_pixels, nrows, ncols, d_slice, d_y, d_cb, d_cr, (hipStream_t)hip_stream));
+  return TOR_OK;
+}
+
 int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out) {
   if (!ctx || !ms_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_kernel_ms: NULL argument");
   if (!ctx->timing_valid) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_kernel_ms: no timed launch");

@@ -60,6 +60,8 @@ hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles,
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
+hipError_t launch_encode_ipcm(const double* pixels, int nrows, int ncols, uint8_t* out, uint8_t* plane_y,
+                              uint8_t* plane_cb, uint8_t* plane_cr, hipStream_t stream);
 hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
                            hipStream_t stream);
 
