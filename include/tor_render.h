@@ -209,6 +209,13 @@ TOR_API int tor_encode_frame_device(TorContext* ctx, const double* d_pixels, int
                                     uint8_t* d_slice, uint8_t* d_y, uint8_t* d_cb, uint8_t* d_cr,
                                     void* hip_stream);
 
+/* The animation driver's loop body in one blocking call (trace_of_radiance_animation.nim:181-196):
+ * render the frame with the uploaded scene, convert + pack it on the device, copy only the slice NAL
+ * unit (tor_h264_frame_bytes() bytes) to slice_out. */
+TOR_API int tor_render_frame_h264(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols,
+                                  int32_t samples_per_pixel, float gamma_correction, int64_t max_depth,
+                                  const TorOptions* opt, uint8_t* slice_out, int64_t cap);
+
 /* Timing of the last tor_render_device call on this context, measured with HIP events
  * recorded on the launch stream around the integrator kernel only (ms); blocks until the
  * kernel has finished.  samples_out (nullable) = pixel-samples that launch traced. */

@@ -83,3 +83,35 @@ def test_device_video_stage_is_byte_exact(tor, oracle):
     with pytest.raises(tor.TorError):
         ctx.encode_frame_device(frame.data_ptr(), 100, 256, out.data_ptr())
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_animation_driver_example_writes_a_valid_stream(tor, oracle, tmp_path):
+    """examples/trace_of_radiance_animation.cpp = main_animation_mp4 (trace_of_radiance_animation.nim:101-214)
+    on the bare C ABI: its .264 file must be header + one slice per frame, and the first frame must be the
+    oracle's encoding of the oracle's render of the first animated scene."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler on this box")
+    exe, out = str(tmp_path / "anim"), str(tmp_path / "a.264")
+    libdir = os.path.dirname(tor.LIB_PATH)
+    subprocess.run(["g++", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "trace_of_radiance_animation.cpp"),
+                    "-L", libdir, "-ltor_mi355x", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                   check=True, capture_output=True)
+    w, h, spp = 64, 32, 2       # int(64 / (16/9)) = 36 is not a multiple of 16 -> the driver must refuse ...
+    r = subprocess.run([exe, out, "64", "2", "0.2"], capture_output=True, timeout=300)
+    assert r.returncode != 0
+    w, h = 256, 144             # ... and run at the reference's fast-test size
+    r = subprocess.run([exe, out, str(w), str(spp), "0.1"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    data = open(out, "rb").read()
+    hdr = tor.h264_stream_header(w, h)
+    fb = tor.h264_frame_bytes(w, h)
+    frames = list(oracle.animation_scenes(h, w, 0.005, 0.0, 0.1, 6))
+    assert data[:len(hdr)] == hdr and len(data) == len(hdr) + len(frames) * fb and len(frames) == 4
+    ocam, oobjs, _ = frames[0]
+    canvas = oracle.render(h, w, spp, ocam, oobjs, seeding=0, math=1, arith=0).pixels
+    assert data[len(hdr):len(hdr) + fb] == oracle.encode_frame(canvas)[4]

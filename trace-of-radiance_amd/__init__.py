@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
-    "tor_encode_frame_device", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_encode_frame_device", "tor_render_frame_h264", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -195,6 +195,8 @@ def lib():
     L.tor_h264_frame_bytes.restype = C.c_int64
     L.tor_encode_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
+    L.tor_render_frame_h264.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int64,
+                                        C.POINTER(Options), C.POINTER(C.c_uint8), C.c_int64]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -463,6 +465,15 @@ class Context:
         _check(lib().tor_encode_frame_device(self._h, C.c_void_p(d_pixels_ptr), nrows, ncols, C.c_void_p(d_slice_ptr),
                                              C.c_void_p(d_y_ptr), C.c_void_p(d_cb_ptr), C.c_void_p(d_cr_ptr),
                                              C.c_void_p(stream_ptr)))
+
+    def render_frame_h264(self, cam: Camera, nrows: int, ncols: int, spp: int, gamma: float, max_depth: int,
+                          options: Options | None = None) -> bytes:
+        """Render the uploaded scene and return the frame's I_PCM slice (animation driver loop body)."""
+        n = h264_frame_bytes(ncols, nrows)
+        buf = (C.c_uint8 * n)()
+        _check(lib().tor_render_frame_h264(self._h, C.byref(cam), nrows, ncols, spp, gamma, int(max_depth),
+                                           C.byref(options) if options is not None else None, buf, n))
+        return bytes(buf)
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -97,6 +97,7 @@ struct TorContext {
   TorCamera cam_host[64];
   std::vector<double> bnd_host[64];
   DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
+  DeviceBuffer slice;     // tor_render_frame_h264's device slice buffer
   bool collect_stats = false;
   static constexpr int kEventRing = 64;
   hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
@@ -203,6 +204,7 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->tile_cost.release();
   ctx->tile_order.release();
   ctx->scratch.release();
+  ctx->slice.release();
   for (int i = 0; i < TorContext::kEventRing; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
     if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -509,6 +511,29 @@ int tor_encode_frame_device(TorContext* ctx, const double* d_pixels, int32_t nro
     return fail(TOR_ERR_INVALID_ARGUMENT, "tor_encode_frame_device: width and height must be multiples of 16");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(tor::launch_encode_ipcm(d_pixels, nrows, ncols, d_slice, d_y, d_cb, d_cr, (hipStream_t)hip_stream));
+  return TOR_OK;
+}
+
+// One turn of the animation driver's loop body (trace_of_radiance_animation.nim:181-196): render the
+// frame, convert and pack it on the device, and hand back only the slice NAL unit (1.5 B per pixel
+// over PCIe instead of the 24 B per pixel canvas).  Blocking.
+int tor_render_frame_h264(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols, int32_t spp,
+                          float gamma_correction, int64_t max_depth, const TorOptions* opt, uint8_t* slice_out,
+                          int64_t cap) {
+  if (!ctx || !cam || !slice_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: NULL argument");
+  const int64_t n = tor_h264_frame_bytes(ncols, nrows);
+  if (n < 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: width and height must be multiples of 16");
+  if (cap < n) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: output buffer too small");
+  if (opt && opt->shard_count > 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: whole frames only");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(ctx->scratch.ensure((size_t)nrows * ncols * 24));
+  HIP_TRY(ctx->slice.ensure((size_t)n));
+  int rc = tor_render_device(ctx, cam, nrows, ncols, spp, gamma_correction, max_depth, opt, (double*)ctx->scratch.ptr, nullptr);
+  if (rc != TOR_OK) return rc;
+  rc = tor_encode_frame_device(ctx, (const double*)ctx->scratch.ptr, nrows, ncols, (uint8_t*)ctx->slice.ptr, nullptr, nullptr,
+                               nullptr, nullptr);
+  if (rc != TOR_OK) return rc;
+  HIP_TRY(hipMemcpy(slice_out, ctx->slice.ptr, (size_t)n, hipMemcpyDeviceToHost));
   return TOR_OK;
 }
 
