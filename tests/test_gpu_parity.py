@@ -401,3 +401,23 @@ def test_block_culling_randomised_scenes(tor, oracle):
         assert np.array_equal(cam.as_array(), ocam)
         want = oracle.render(h, w, spp, ocam, recs, max_depth=12, seeding=seeding, math=1, arith=0, accum=seeding).pixels
         _assert_parity(base.pixels, want)
+
+
+def test_full_c2_frame_matches_oracle(tor, oracle, ref_scene, ref_camera):
+    """BASELINE configs[1] in full: 1920x1080, 100 spp, depth 50 with the reference's per-pixel streams
+    (tor_render semantics, cost-ordered tiles) -- all 6 220 800 float64 channel values against the oracle
+    (about a minute of CPU on the GPU box), plus the culled variant on the same frame."""
+    import torch
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    ctx = tor.Context()
+    ctx.upload(scene.list())
+    h, w, spp = 1080, 1920, 100
+    want = oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=1, arith=0).pixels
+    for accel in (tor.ACCEL_NONE, tor.ACCEL_BLOCKS):
+        buf = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        ctx.render_device(cam, h, w, spp, 2.2, 50, tor.make_options(seeding=tor.SEED_PIXEL, accel=accel), buf.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        _assert_parity(buf.cpu().numpy(), want)
+    ctx.close()
