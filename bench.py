@@ -63,15 +63,19 @@ def parse_args():
     return ap.parse_args()
 
 
-def measured_traffic(W, H, spp, seeding, arith):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json), for the configurations that were profiled; None otherwise."""
+def measured_profile(W, H, spp, seeding, arith):
+    """What the committed rocprofv3 PMC passes (profiles/traffic.json) measured for this configuration:
+    HBM bytes per launch of the dominant kernel and its executed-instruction counters; {} otherwise."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        return t[f"{W}x{H}x{spp}:{seeding}:{arith}"]["bytes"]
+        return t[f"{W}x{H}x{spp}:{seeding}:{arith}"]
     except Exception:
-        return None
+        return {}
+
+
+def measured_traffic(W, H, spp, seeding, arith):
+    return measured_profile(W, H, spp, seeding, arith).get("bytes")
 
 
 def cpu_baseline(width, height, spp, depth, target_seconds):
@@ -253,6 +257,7 @@ def main():
             "nofma_peak": PEAK_FP64_NOFMA_TFLOPS,
             "flops_per_sample": FLOPS_PER_SAMPLE, "kernel_ms": round(k_ms, 3), "launches_averaged": k_n,
             "traffic": measured_traffic(W, H, spp, args.seeding, args.arith) if world == 1 else None,
+            "executed": measured_profile(W, H, spp, args.seeding, args.arith).get("executed") if world == 1 else None,
             "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 4), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 8),
                     "algorithmic_bytes_per_launch": hbm_bytes},
