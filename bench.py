@@ -10,7 +10,7 @@ depth 50, rendered with the counter-based per-sample streams (TOR_SEED_SAMPLE) a
 reference's rounding (TOR_ARITH_STRICT).  Scene and camera are resident in HBM before the timed
 region; the frame stays on the device.
 
-N > 1 (one process per GPU, RCCL): image rows are dealt to the ranks in tiles (render.nim:55's
+N > 1 (one process per GPU, RCCL): image rows are dealt to the ranks round-robin (render.nim:55's
 `parallelFor row` across GPUs), every rank renders its rows, then ONE all_gather of the
 row shards (the framebuffer gather over xGMI) -- both inside the timed region.  Weak scaling:
 samples per pixel grow with N (100*N), so every GPU traces the same number of samples as the
@@ -52,7 +52,8 @@ def parse_args():
     ap.add_argument("--arith", choices=["strict", "fused"], default="strict")
     ap.add_argument("--accel", choices=["none", "blocks"], default="none",
                     help="none: the reference's brute-force closest hit (the metric's algorithm); blocks: exact block culling (SURVEY 8 f4)")
-    ap.add_argument("--row-tile", type=int, default=8)
+    ap.add_argument("--row-tile", type=int, default=1,
+                    help="rows per shard tile; 1 = row-cyclic: every rank gets nrows/N rows (+-1) of statistically equal cost")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
@@ -265,7 +266,7 @@ def main():
                     "per pixel); the reference's arithmetic has no FMA, so 0.5 of the FMA peak is its ceiling",
         }
         result = {
-            "metric": "Msamples/s (pixels x spp / s) on random_scene", "value": round(value, 2), "unit": "Msamples/s",
+            "metric": "Msamples/s (pixels\u00d7spp/s) on book-1 random_scene", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -1,0 +1,68 @@
+"""The drop-in boundary without a GPU: libtor_mi355x.so loads, exports every symbol that
+include/tor_render.h declares, mirrors the reference's struct layouts, and refuses to render on a
+machine without a HIP device (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tor_render.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"TOR_API\s+[\w\s\*]+?\b(tor_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(tor):
+    names = _declared_symbols()
+    assert len(names) >= 25 and "tor_render" in names and "tor_render_device" in names
+    L = tor.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/tor_render.h but not exported"
+    assert sorted(tor.EXPORTED_SYMBOLS) == names, "the Python binding list drifted from the header"
+    assert L.tor_version().startswith(b"tor_mi355x")
+
+
+def test_struct_layouts_mirror_the_reference(tor):
+    # sizes Nim's C backend derives on x86-64: Canvas 24, Camera 192, HittableList 16,
+    # HittableVariant 120 (kind @0, union @8), Sphere 72, MovingSphere 112, Material 40 (kind @0, union @8)
+    assert C.sizeof(tor.CanvasStruct) == 24 and C.sizeof(tor.Camera) == 192 and C.sizeof(tor.HittableList) == 16
+    assert C.sizeof(tor.HittableVariant) == 120 and tor.HittableVariant.u.offset == 8
+    assert C.sizeof(tor.Sphere) == 72 and C.sizeof(tor.MovingSphere) == 112
+    assert C.sizeof(tor.Material) == 40 and tor.Material.u.offset == 8
+    assert tor.MovingSphere.time0.offset == 48 and tor.MovingSphere.radius.offset == 64 and tor.MovingSphere.material.offset == 72
+    assert tor.Camera.lens_radius.offset == 168 and tor.Camera.shutter_close.offset == 184
+
+
+def test_host_mirrors_and_row_sharding_work_without_a_gpu(tor, oracle):
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    objs, _ = oracle.random_scene(0xFACADE)
+    assert len(scene) == 485 and np.array_equal(scene.to_records(), objs)
+    assert np.array_equal(cam.as_array(), oracle.camera())
+    assert tor.selftest_rng(1, 0xFACADE, n=1)[1] == [0xff30ded049ef2d99]
+    rows = [tor.shard_rows(1080, 1, k, 8) for k in range(8)]      # row-cyclic: the bench default
+    assert sorted(np.concatenate(rows).tolist()) == list(range(1080)) and all(len(r) == 135 for r in rows)
+    rows = [tor.shard_rows(1080, 8, k, 8) for k in range(8)]      # tiles of 8 rows do not divide evenly
+    assert sorted(np.concatenate(rows).tolist()) == list(range(1080)) and sorted({len(r) for r in rows}) == [128, 136]
+    cv = tor.new_canvas(4, 4, 1)
+    cv.pixels[:] = [[[0.0, 0.5, 1.0]] * 4] * 4
+    assert tor.export_rgb8(cv)[0, 0].tolist() == [0, 128, 255]
+
+
+def test_rendering_fails_loudly_without_a_device(tor):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = tor.new_canvas(8, 8, 1)
+    cv.pixels[:] = 3.0
+    with pytest.raises(tor.TorError) as e:
+        tor.render(cv, cam, scene.list(), 5)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    assert np.all(cv.pixels == 3.0)
+    with pytest.raises(tor.TorError):
+        tor.Context()
