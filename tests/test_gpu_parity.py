@@ -378,8 +378,9 @@ def test_block_culling_randomised_scenes(tor, oracle):
     culled render is bit-identical to the brute-force render; one configuration per scene is also
     checked against the oracle."""
     rng = np.random.default_rng(20260928)
-    for trial in range(14):
-        n = int(rng.integers(64, 420))
+    for trial in range(16):
+        # the last two scenes are large enough (> 96 blocks) for the second box level
+        n = int(rng.integers(64, 420)) if trial < 14 else int(rng.integers(900, 1300))
         spread = float(rng.choice([3.0, 6.0, 12.0]))
         recs = _random_records(rng, n, spread, with_big=bool(trial % 2))
         scene = tor.Scene.from_records(recs)

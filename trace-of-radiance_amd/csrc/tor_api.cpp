@@ -259,7 +259,8 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
     HIP_TRY(put(ctx->a_hot, ctx->accel.hot));
     HIP_TRY(put(ctx->a_grp, ctx->accel.groups));
     const size_t n_bnd_p = (ctx->accel.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
-    ctx->bnd_slot_bytes = (8 * n_bnd_p + 16) * 8;
+    const size_t n_super_p = (n_bnd_p / tor::kPad + tor::kPad - 1) / tor::kPad * tor::kPad;
+    ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * 8;
     HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
   }
   ctx->n_objects = n;

@@ -336,10 +336,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
             }
-          } else if (seg_kind == 3) {
+          } else if (seg_kind == 3 || seg_kind == 4) {
             // TOR_ACCEL_BLOCKS: the records are inflated axis-aligned boxes around spatial blocks of 8
-            // objects.  Slab test; a set bit means 'this lane has to look inside that block' and the
-            // entry is flagged with bit 31.  1/d may be +-inf (d = 0): (lo - o) * inf is +-inf, or
+            // objects (kind 3, entries flagged with bit 31) or around 8 such blocks (kind 4, bit 30).
+            // Slab test; a set bit means 'this lane has to look inside'.  1/d may be +-inf (d = 0): (lo - o) * inf is +-inf, or
             // NaN when lo == o, and v_min/v_max_f64 drop a NaN operand -- the axis then imposes no
             // constraint, which is the conservative answer.
             const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 m = (m << 1) | ((t_in <= t_out) ? 1u : 0u);
               }
               rec += 8 * kBlock;
-              q[qn * 64] = 0x80000000u | ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+              q[qn * 64] = ((seg_kind == 3) ? 0x80000000u : 0x40000000u) | ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
             }
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           if (cur_mask == 0 && kq < qn) {
             const unsigned e = q[kq * 64];
             kq += 1;
-            cur_is_bound = e >> 31;
-            cur_block = (e >> 8) & 0x7fffffu;
+            cur_is_bound = e >> 30;  // 0: object mask, 2: block boxes, 1: super boxes
+            cur_block = (e >> 8) & 0x3fffffu;
             cur_mask = e & 0xffu;
           }
           const bool has = cur_mask != 0;
@@ -488,8 +488,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             cur_mask &= ~(1u << b);
             const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
             if (cur_is_bound) {
-              // ---- spatial block `rec`: filter its 8 objects, then exact roots for the survivors
-              auto expand = [&](auto blk, auto HS) {
+              // ---- spatial block `blk_id`: filter its 8 objects, then exact roots for the survivors
+              auto expand = [&](auto blk, auto HS, unsigned blk_id) {
                 constexpr int hs = decltype(HS)::value;
                 unsigned m8 = 0;
 #pragma unroll
@@ -504,18 +504,44 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   const int j = 7 - bb;
                   double cx, cy, cz, f;
                   spatial_center(blk + hs * j, HS, cx, cy, cz, f);
-                  exact_hit(cx, cy, cz, blk[hs * j + 3], (unsigned)p.spatial_base + rec * kBlock + (unsigned)j, f);
+                  exact_hit(cx, cy, cz, blk[hs * j + 3], (unsigned)p.spatial_base + blk_id * kBlock + (unsigned)j, f);
                 }
               };
-              st_cand += kBlock;
               using S8 = std::integral_constant<int, 8>;
               using S4 = std::integral_constant<int, 4>;
-              if (p.shot_stride == 8) {
-                if (staged) expand(shot_lds + (size_t)rec * (8 * kBlock), S8{});            // ds_read
-                else expand((gdptr)(uintptr_t)p.shot + (size_t)rec * (8 * kBlock), S8{});  // global_load
+              auto expand_block = [&](unsigned blk_id) {
+                st_cand += kBlock;
+                if (p.shot_stride == 8) {
+                  if (staged) expand(shot_lds + (size_t)blk_id * (8 * kBlock), S8{}, blk_id);            // ds_read
+                  else expand((gdptr)(uintptr_t)p.shot + (size_t)blk_id * (8 * kBlock), S8{}, blk_id);  // global_load
+                } else {
+                  if (staged) expand(shot_lds + (size_t)blk_id * (4 * kBlock), S4{}, blk_id);
+                  else expand((gdptr)(uintptr_t)p.shot + (size_t)blk_id * (4 * kBlock), S4{}, blk_id);
+                }
+              };
+              if (cur_is_bound == 2) {
+                expand_block(rec);
               } else {
-                if (staged) expand(shot_lds + (size_t)rec * (4 * kBlock), S4{});
-                else expand((gdptr)(uintptr_t)p.shot + (size_t)rec * (4 * kBlock), S4{});
+                // super box `rec`: slab-test its 8 block boxes, descend into the ones the ray can touch
+                const gdptr cb = (gdptr)(uintptr_t)p.bnd + (size_t)rec * (8 * kBlock);
+                const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
+                unsigned mc = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock; ++j) {
+                  const double tx0 = (cb[8 * j + 0] - ox) * ix, tx1 = (cb[8 * j + 3] - ox) * ix;
+                  const double ty0 = (cb[8 * j + 1] - oy) * iy, ty1 = (cb[8 * j + 4] - oy) * iy;
+                  const double tz0 = (cb[8 * j + 2] - oz) * iz, tz1 = (cb[8 * j + 5] - oz) * iz;
+                  const double t_in = __builtin_fmax(__builtin_fmax(__builtin_fmin(tx0, tx1), __builtin_fmin(ty0, ty1)),
+                                                     __builtin_fmax(__builtin_fmin(tz0, tz1), 0.0));
+                  const double t_out = __builtin_fmin(__builtin_fmin(__builtin_fmax(tx0, tx1), __builtin_fmax(ty0, ty1)),
+                                                      __builtin_fmax(tz0, tz1));
+                  mc = (mc << 1) | ((t_in <= t_out) ? 1u : 0u);
+                }
+                while (mc != 0) {
+                  const int cbit = 31 - __builtin_clz(mc);
+                  mc &= ~(1u << cbit);
+                  expand_block(rec * kBlock + (unsigned)(7 - cbit));
+                }
               }
             } else {
               st_cand += 1;

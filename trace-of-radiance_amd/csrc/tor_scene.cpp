@@ -266,7 +266,15 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
   // the bounds segment (kind 3): records live in KParams.bnd, one per block, padded to 8
   const size_t n_bnd_p = (out.n_blocks + kPad - 1) / kPad * kPad;
   if (out.always.n_segs == 0) out.always.segs.clear();
-  out.always.segs.insert(out.always.segs.end(), {3.0, 0.0, (double)n_bnd_p, 0.0, 0.0, 0.0, 0.0, 0.0});
+  // few blocks: the wave-uniform loop tests the block boxes themselves (kind 3); otherwise it tests
+  // the super boxes (kind 4: first record n_bnd_p + 1 of the bounds array) and the lanes descend
+  const size_t n_super = n_bnd_p / kPad;
+  const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;
+  out.two_level = out.n_blocks > 96;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
+  if (out.two_level)
+    out.always.segs.insert(out.always.segs.end(), {4.0, (double)(n_bnd_p + 1), (double)n_super_p, 0.0, 0.0, 0.0, 0.0, 0.0});
+  else
+    out.always.segs.insert(out.always.segs.end(), {3.0, 0.0, (double)n_bnd_p, 0.0, 0.0, 0.0, 0.0, 0.0});
   out.always.n_segs += 1;
   out.hot_stride = 8;
   if (out.groups.empty()) {
@@ -319,6 +327,26 @@ bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::v
       bnd[8 * b + a] = lo[a] - pad;
       bnd[8 * b + 3 + a] = hi[a] + pad;
     }
+  }
+  // second level: one box around every 8 consecutive block boxes (the blocks follow the Morton
+  // curve, so the groups are compact); stored behind the block boxes, padded with NaN boxes
+  const size_t n_super = n_bnd_p / kPad;
+  const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;
+  const size_t super0 = n_bnd_p + 1;  // record index of the first super box (one slack record in between)
+  bnd.resize(8 * (super0 + n_super_p + 1), 0.0);
+  for (size_t sidx = 0; sidx < n_super_p + 1; ++sidx)
+    for (int a = 0; a < 6; ++a) bnd[8 * (super0 + sidx) + a] = qnan;
+  for (size_t sidx = 0; sidx < n_super; ++sidx) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool any = false;
+    for (int j = 0; j < kPad; ++j) {
+      const double* c = &bnd[8 * (sidx * kPad + j)];
+      if (c[0] != c[0]) continue;  // NaN: empty child
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[3 + a]); }
+      any = true;
+    }
+    if (!any) continue;
+    for (int a = 0; a < 3; ++a) { bnd[8 * (super0 + sidx) + a] = lo[a]; bnd[8 * (super0 + sidx) + 3 + a] = hi[a]; }
   }
   return true;
 }

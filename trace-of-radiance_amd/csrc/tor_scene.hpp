@@ -35,6 +35,7 @@ struct HostAccel {
   std::vector<double> groups;   // {time0, time1 - time0} per time group of the spatial objects
   size_t spatial_base = 0;      // first cold slot of the spatial objects (multiple of 8)
   size_t n_blocks = 0;
+  bool two_level = false;       // the uniform loop tests boxes around 8 blocks; lanes descend to the block boxes
   struct Obj { double c0[3], dc[3], t0, dt, abs_r; bool moving, valid; };
   std::vector<Obj> spatial;     // n_blocks * 8 entries (padding: valid = false)
 };
@@ -42,7 +43,8 @@ struct HostAccel {
 void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out);
 
 // 8 float64 per block {lo xyz, hi xyz, 0, 0}: a conservative (inflated) axis-aligned box around the
-// block's spheres over the ray-time range; padded to a multiple of 8 blocks with never-entered boxes.
+// block's spheres over the ray-time range; padded to a multiple of 8 blocks with never-entered (NaN)
+// boxes; then one slack record and the super boxes (one per 8 block boxes, again padded to 8).
 // Returns false when the time range is not finite (caller falls back to brute force).
 bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::vector<double>& bnd);
 
