@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
                     help="c2: random_scene frame (default, the metric's config); c5: BASELINE configs[4], the animated "
                          "bouncing-spheres scene, 256 spp per frame, frames dealt round-robin to the GPUs (no collective)")
+    ap.add_argument("--verify", action="store_true", help="N > 1: also render the whole frame on every rank and require the gathered frame to be identical")
     ap.add_argument("--no-accel-leg", action="store_true", help="skip the secondary TOR_ACCEL_BLOCKS measurement")
     ap.add_argument("--stats", action="store_true", help="also collect the kernel's workload counters (untimed extra step)")
     return ap.parse_args()
@@ -134,7 +135,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
             break
         if f % max(world, 1) == (rank if world > 1 else 0):
             frames.append((cam, scene))
-    ctx = tor.Context(local_rank if world > 1 else 0)
+    ctx = tor.Context(local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0)
     opt = tor.make_options(seeding=seeding, arith=arith, accel=tor.ACCEL_BLOCKS if args.accel == "blocks" else tor.ACCEL_NONE)
     buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -186,12 +187,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
+    # TOR_BENCH_BACKEND=gloo lets several ranks share ONE GPU (testing the N > 1 path on a 1-GPU box);
+    # the real run is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("TOR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
+        dev_index = 0
     tor = importlib.import_module("trace-of-radiance_amd")
 
     H, W = args.height, args.width
@@ -203,7 +212,7 @@ def main():
 
     scene = tor.random_scene(0xFACADE)
     cam = tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
-    ctx = tor.Context(local_rank if world > 1 else 0)
+    ctx = tor.Context(dev_index)
     ctx.upload(scene.list())
     opt = tor.make_options(seeding=seeding, arith=arith, shard_index=rank if world > 1 else 0,
                            shard_count=max(world, 1), row_tile=args.row_tile,
@@ -238,6 +247,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if args.verify and world > 1:
+        # the gathered frame must be the frame one process renders alone (any partition, any world size)
+        full = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+        ctx.render_device(cam, H, W, spp, 2.2, args.depth,
+                          tor.make_options(seeding=seeding, arith=arith, accel=opt.accel), full.data_ptr(), stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(full, frame.frame))
+        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
+        if not verified:
+            raise SystemExit(f"rank {rank}: gathered frame differs from the single-process frame")
+    else:
+        verified = None
 
     # dominant kernel: integrate_kernel, per-launch HIP events on the launch stream
     k_ms, k_n = ctx.kernel_ms_mean(args.steps)
@@ -277,6 +301,8 @@ def main():
                                       (" + RCCL all_gather of the framebuffer" if world > 1 else "")},
             "roofline": roof,
         }
+        if verified is not None:
+            result["gathered_frame_identical_to_single_process"] = verified
     if rank == 0 and world == 1 and args.accel == "none" and not args.no_accel_leg:
         # secondary leg (never the metric's value): the same frame with TOR_ACCEL_BLOCKS -- exact block
         # culling, bit-identical canvas (tests/test_gpu_parity.py::test_block_culling_never_changes_a_pixel)

@@ -422,3 +422,24 @@ def test_full_c2_frame_matches_oracle(tor, oracle, ref_scene, ref_camera):
         torch.cuda.synchronize()
         _assert_parity(buf.cpu().numpy(), want)
     ctx.close()
+
+
+def test_bench_multi_rank_path_on_one_gpu(tor):
+    """bench.py's N > 1 path (row-cyclic shards, per-rank render, all_gather of the shards, row assembly,
+    max-over-ranks timing) with 2 ranks sharing this box's single GPU over gloo; --verify makes every rank
+    compare the gathered frame with the frame it renders alone.  (The real run is one rank per GPU, RCCL.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + os.getpid() % 300
+    env = dict(os.environ, TOR_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "1", "--spp", "4", "--width", "640", "--height", "360", "--verify"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["gathered_frame_identical_to_single_process"] is True
+    assert d["scaling"] == "weak" and "8 spp (4 per GPU)" in d["config"]["workload"] and d["value"] > 0

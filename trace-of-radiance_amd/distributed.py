@@ -55,9 +55,16 @@ class DistributedFrame:
         self._idx = [torch.as_tensor(plan.rows[k], device=device) for k in range(plan.world)]
 
     def gather(self):
+        import torch
         import torch.distributed as dist
         if self.plan.world > 1:
-            dist.all_gather_into_tensor(self._gathered_flat, self.send)
+            if dist.get_backend() == "gloo" and self.send.is_cuda:
+                # test configuration only (several ranks sharing one GPU): gloo gathers host tensors
+                host = torch.empty(self._gathered_flat.shape, dtype=self.send.dtype)
+                dist.all_gather_into_tensor(host, self.send.cpu())
+                self._gathered_flat.copy_(host)
+            else:
+                dist.all_gather_into_tensor(self._gathered_flat, self.send)
             for k in range(self.plan.world):
                 self.frame.index_copy_(0, self._idx[k], self.gathered[k, : len(self.plan.rows[k])])
         else:
