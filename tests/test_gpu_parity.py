@@ -224,12 +224,14 @@ def test_edge_cases_match_oracle(tor, oracle, ref_camera):
     # max_depth = 0: the bounce loop never runs -> black canvas (render.nim:25,47)
     cv = _render(tor, scene, cam, 8, 8, 4, 0)
     assert np.array_equal(cv.pixels, np.zeros((8, 8, 3)))
-    # many objects: queue overflow path (every sphere encloses the camera -> all are candidates)
-    big = [[0, 13, 2, 3, 13, 2, 3, 0, 1, 5.0 + 0.01 * i, 2, 0, 0, 0, 0, 1.5] for i in range(100)]
+    # queue overflow path: every sphere encloses the camera -> all 300 are candidates -> 38 mask entries
+    # per lane against a queue of 16: the object loop has to stop, resolve and resume (twice)
+    big = [[0, 13, 2, 3, 13, 2, 3, 0, 1, 5.0 + 0.01 * i, 2, 0, 0, 0, 0, 1.5] for i in range(300)]
     scene2, recs2 = _custom_scene(tor, oracle, big)
-    cv = _render(tor, scene2, cam, 6, 6, 2, 8, seeding=1)
     want = oracle.render(6, 6, 2, ref_camera, recs2, max_depth=8, seeding=1, math=1, accum=1).pixels
-    _assert_parity(cv.pixels, want)
+    for accel in (tor.ACCEL_NONE, tor.ACCEL_BLOCKS):
+        cv = _render(tor, scene2, cam, 6, 6, 2, 8, seeding=1, accel=accel)
+        _assert_parity(cv.pixels, want)
 
 
 def test_invalid_arguments_fail_loudly(tor):
