@@ -244,7 +244,8 @@ class Scene:
 
     @staticmethod
     def from_records(recs: np.ndarray) -> "Scene":
-        """Build from the oracle's flat (n,16) float64 records (tests only)."""
+        """Build from flat (n,16) float64 records {kind, c0 xyz, c1 xyz, t0, t1, radius, material, albedo rgb, fuzz, ri}
+        (the interchange format of the parity tests)."""
         n = int(recs.shape[0])
         arr = (HittableVariant * max(n, 1))()
         for i in range(n):
@@ -275,7 +276,7 @@ class Scene:
         return Scene(arr, n)
 
     def to_records(self) -> np.ndarray:
-        """Flat (n,16) float64 records in the oracle's field order (tests only)."""
+        """The scene as flat (n,16) float64 records (see from_records)."""
         out = np.zeros((self.n, 16), dtype=np.float64)
         for i in range(self.n):
             h = self.objects[i]
