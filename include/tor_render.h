@@ -276,6 +276,14 @@ TOR_API int tor_canvas_to_rgb8(const TorCanvas* canvas, uint8_t* out);
 /* Self-test probes (used by the parity tests; no effect on rendering)                   */
 /* ------------------------------------------------------------------------------------ */
 
+/* Host-only debug view of the TOR_ACCEL_BLOCKS layout for a ray-time range: slot_object[k] = original index
+ * of the object in spatial slot k (block k/8) or -1; block_boxes / super_boxes = 6 float64 {lo xyz, hi xyz}
+ * per (padded) block / per group of 8 blocks.  Returns the number of blocks (0 when no culling layout is
+ * built for this scene) or a negative status. */
+TOR_API int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_hi, int64_t* slot_object,
+                                   int64_t slot_cap, double* block_boxes, double* super_boxes, int64_t box_cap,
+                                   int32_t* two_level_out);
+
 /* Runs the kernel's own math on the DEVICE: op 0: sin,cos(a)  1: x^5  2: pow(x,y)
  * 3: sqrt(x)  4: x/y  5: uniform01 of seed(row=x,col=y) first n draws... see tests. */
 TOR_API int tor_selftest_math_device(int32_t op, const double* x, const double* y, double* out0,

@@ -1,0 +1,63 @@
+"""TOR_ACCEL_BLOCKS is exact only if its boxes are conservative.  This CPU test (no GPU) takes the layout the
+library builds and checks the invariant directly: every object sits in exactly one place (a spatial slot or
+the always-list), every spatial object's swept sphere over the ray-time range lies strictly inside its block's
+box, and every block box inside its super box."""
+import numpy as np
+import pytest
+
+
+def _scene(tor, rng, n, spread):
+    recs = [[0, 0, -500, 0, 0, -500, 0, 0, 1, 500, 0, .5, .5, .5, 0, 0]]
+    groups = [(0.0, 1.0), (-0.5, 0.5), (0.25, 2.0), (1.0, 0.0)]
+    while len(recs) < n:
+        x, y, z = rng.uniform(-spread, spread), rng.uniform(0, 0.3 * spread), rng.uniform(-spread, spread)
+        r = float(rng.choice([0.15, 0.2, 0.3, 0.45])) * (1 if rng.random() > 0.05 else -1)
+        if rng.random() < 0.4:
+            recs.append([0, x, y, z, x, y, z, 0, 1, r, 0, .5, .5, .5, 0, 0])
+        else:
+            t0, t1 = groups[int(rng.integers(0, 4))]
+            d = rng.uniform(-0.6, 0.6, 3)
+            recs.append([1, x, y, z, x + d[0], y + d[1], z + d[2], t0, t1, r, 1, .5, .5, .5, 0.1, 0])
+    recs.append([1, 1, 1, 1, 2, 2, 2, 0.5, 0.5, 0.3, 0, .1, .9, .1, 0, 0])   # time0 == time1 -> always-list
+    return np.asarray(recs, dtype=np.float64)
+
+
+@pytest.mark.parametrize("n,spread,shutter", [(120, 4.0, (0.0, 1.0)), (485, 11.0, (0.0, 1.0)), (700, 8.0, (-2.0, 3.0)),
+                                              (1500, 20.0, (0.0, 0.0)), (2100, 15.0, (0.3, 0.1))])
+def test_boxes_are_conservative(tor, n, spread, shutter):
+    rng = np.random.default_rng(n)
+    recs = _scene(tor, rng, n, spread)
+    scene = tor.Scene.from_records(recs)
+    t_lo, t_hi = min(0.0, *shutter), max(0.0, *shutter)
+    lay = tor.debug_accel_layout(scene.list(), t_lo, t_hi)
+    assert lay is not None
+    slots, boxes, supers, two_level = lay
+    assert two_level == (slots.shape[0] > 96)
+    placed = slots[slots >= 0]
+    assert len(set(placed.tolist())) == len(placed)                       # no object twice
+    always = sorted(set(range(len(recs))) - set(placed.tolist()))
+    big_or_degenerate = [i for i in range(len(recs)) if abs(recs[i, 9]) > 2.5 * np.median(np.abs(recs[:, 9]))
+                         or (recs[i, 0] == 1 and recs[i, 8] == recs[i, 7])]
+    assert always == sorted(big_or_degenerate)                            # only those stay brute force
+    ts = np.linspace(t_lo, t_hi, 7)
+    for b in range(slots.shape[0]):
+        lo, hi = boxes[b, :3], boxes[b, 3:]
+        for i in slots[b][slots[b] >= 0]:
+            r = recs[i]
+            c0, c1, rad = r[1:4], r[4:7], abs(r[9])
+            for t in ts:
+                f = (t - r[7]) / (r[8] - r[7]) if r[0] == 1 else 0.0
+                c = c0 + f * (c1 - c0)
+                assert np.all(c - rad > lo) and np.all(c + rad < hi), (b, i, t)
+        s = supers[b // 8]
+        assert np.all(s[:3] <= lo) and np.all(s[3:] >= hi)
+    # padding blocks are NaN boxes (never entered; an inverted box would be)
+    assert np.all(np.isnan(boxes[slots.shape[0]:]))
+
+
+def test_small_scenes_have_no_second_level(tor):
+    scene = tor.Scene.from_records(_scene(tor, np.random.default_rng(1), 40, 3.0))
+    assert tor.debug_accel_layout(scene.list(), 0.0, 1.0) is None
+    # a non-finite shutter cannot be bounded: the library falls back to brute force
+    scene = tor.Scene.from_records(_scene(tor, np.random.default_rng(2), 200, 3.0))
+    assert tor.debug_accel_layout(scene.list(), 0.0, float("inf")) is None

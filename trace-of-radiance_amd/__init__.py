@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
-    "tor_encode_frame_device", "tor_render_frame_h264", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_encode_frame_device", "tor_render_frame_h264", "tor_debug_accel_layout", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -197,6 +197,8 @@ def lib():
                                           C.c_void_p, C.c_void_p]
     L.tor_render_frame_h264.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int64,
                                         C.POINTER(Options), C.POINTER(C.c_uint8), C.c_int64]
+    L.tor_debug_accel_layout.argtypes = [HittableList, C.c_double, C.c_double, C.POINTER(C.c_int64), C.c_int64,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -499,6 +501,24 @@ class Context:
         st = Stats()
         _check(lib().tor_last_stats(self._h, C.byref(st)))
         return st
+
+
+def debug_accel_layout(world: HittableList, t_lo: float, t_hi: float):
+    """(slot_object[n_blocks, 8], block_boxes[n_blocks_padded, 6], super_boxes[n, 6], two_level) or None."""
+    cap = int(world.len) + 64
+    slots = np.full(cap, -1, dtype=np.int64)
+    boxes = np.zeros((cap // 8 + 16, 6), dtype=np.float64)
+    supers = np.zeros((cap // 64 + 16, 6), dtype=np.float64)
+    two = C.c_int32(0)
+    n = lib().tor_debug_accel_layout(world, t_lo, t_hi, slots.ctypes.data_as(C.POINTER(C.c_int64)), cap,
+                                     boxes.ctypes.data_as(C.POINTER(C.c_double)),
+                                     supers.ctypes.data_as(C.POINTER(C.c_double)), boxes.shape[0], C.byref(two))
+    if n < 0:
+        raise TorError(n, "tor_debug_accel_layout failed")
+    if n == 0:
+        return None
+    n_p = (n + 7) // 8 * 8
+    return slots[: n * 8].reshape(n, 8), boxes[:n_p], supers[: n_p // 8], bool(two.value)
 
 
 def selftest_math(op: int, x: np.ndarray, y: np.ndarray | None = None, where: str = "device", device: int = -1):

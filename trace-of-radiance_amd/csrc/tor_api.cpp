@@ -645,6 +645,35 @@ int tor_render(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, i
   return tor_render_opt(canvas, cam, world, max_depth, nullptr);
 }
 
+// Debug view of the TOR_ACCEL_BLOCKS layout (host only, no device needed): for the given object list and
+// ray-time range, writes per spatial slot the original object index (-1 for padding) and per block its
+// box {lo xyz, hi xyz}, then the super boxes.  Returns the number of blocks (0: no second level is built),
+// or a negative status.  Used by the CPU test that checks the boxes are conservative.
+int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_hi, int64_t* slot_object, int64_t slot_cap,
+                           double* block_boxes, double* super_boxes, int64_t box_cap, int32_t* two_level_out) {
+  if (world.len < 0 || (world.len > 0 && !world.objects)) return TOR_ERR_INVALID_ARGUMENT;
+  tor::HostAccel acc;
+  tor::build_accel(world.objects, world.len, acc);
+  if (!acc.available) return 0;
+  std::vector<double> bnd;
+  if (!tor::compute_block_bounds(acc, t_lo, t_hi, bnd)) return 0;
+  const int64_t n_blocks = (int64_t)acc.n_blocks;
+  const int64_t n_bnd_p = (n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
+  if (slot_cap < n_blocks * tor::kPad || box_cap < n_bnd_p) return TOR_ERR_INVALID_ARGUMENT;
+  for (int64_t k = 0; k < n_blocks * tor::kPad; ++k) {
+    int64_t orig = -1;
+    if (acc.spatial[(size_t)k].valid) std::memcpy(&orig, &acc.cold[16 * (acc.spatial_base + (size_t)k) + 14], 8);
+    slot_object[k] = orig;
+  }
+  for (int64_t b = 0; b < n_bnd_p; ++b)
+    for (int c = 0; c < 6; ++c) block_boxes[6 * b + c] = bnd[8 * (size_t)b + c];
+  const int64_t n_super = n_bnd_p / tor::kPad;
+  for (int64_t sidx = 0; sidx < n_super; ++sidx)
+    for (int c = 0; c < 6; ++c) super_boxes[6 * sidx + c] = bnd[8 * (size_t)(n_bnd_p + 1 + sidx) + c];
+  if (two_level_out) *two_level_out = acc.two_level ? 1 : 0;
+  return (int)n_blocks;
+}
+
 // ---- self tests -----------------------------------------------------------------------------
 
 int tor_selftest_math_host(int32_t op, const double* x, const double* y, double* out0, double* out1,
