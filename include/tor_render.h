@@ -284,6 +284,14 @@ TOR_API int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_
                                    int64_t slot_cap, double* block_boxes, double* super_boxes, int64_t box_cap,
                                    int32_t* two_level_out);
 
+/* TOR_ACCEL_F32 self test on the HOST (same source as the kernel's pre-filter): ray i against sphere i with
+ * centre c0 + dc * f (moving != 0) or c0.  keep[i] = pre-filter keeps the object; need[i] bit 0 = the
+ * float64 test D > 0 and (half_b < 0 or c < 0) holds, bit 1 = the reference's hit() accepts a root.
+ * The filter is correct iff need[i] != 0 implies keep[i] != 0. */
+TOR_API int tor_selftest_filter32_host(int64_t n, const double* o, const double* d, const double* c0,
+                                       const double* dc, const int32_t* moving, const double* f, const double* r2,
+                                       const double* origin, int32_t* keep, int32_t* need);
+
 /* Runs the kernel's own math on the DEVICE: op 0: sin,cos(a)  1: x^5  2: pow(x,y)
  * 3: sqrt(x)  4: x/y  5: uniform01 of seed(row=x,col=y) first n draws... see tests. */
 TOR_API int tor_selftest_math_device(int32_t op, const double* x, const double* y, double* out0,

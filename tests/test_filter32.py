@@ -1,0 +1,96 @@
+"""TOR_ACCEL_F32: the float32 pre-filter may keep too much, never too little.  Host build of the kernel's own
+filter source (tor_filter32.hpp) against the float64 test of spheres.nim:30-33, on random and adversarial
+ray/sphere pairs: tangent rays, origins on the surface (the state after every bounce), far-away and tiny
+objects, short direction vectors, moving centres.  CPU only."""
+import numpy as np
+import pytest
+
+
+def _unit(rng, n):
+    v = rng.normal(size=(n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def _cases(rng, n, scale, r_lo, r_hi, origin):
+    """rays aimed at (or just past) spheres around `origin`; returns o, d, c0, dc, moving, f, r2."""
+    c0 = origin + rng.uniform(-scale, scale, size=(n, 3))
+    moving = (rng.random(n) < 0.6).astype(np.int32)
+    dc = rng.uniform(-0.5, 0.5, size=(n, 3)) * moving[:, None]
+    f = rng.uniform(-0.2, 1.2, size=n) * moving
+    r = rng.uniform(r_lo, r_hi, size=n)
+    c = c0 + dc * f[:, None]
+    o = origin + rng.uniform(-scale, scale, size=(n, 3))
+    kind = rng.integers(0, 5, size=n)
+    # aim: a point at distance r * (1 + eps) from the centre, perpendicular to the view direction -> near tangent
+    to_c = c - o
+    dist = np.linalg.norm(to_c, axis=1, keepdims=True)
+    w = to_c / dist
+    perp = np.cross(w, _unit(rng, n))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    eps = np.where(kind == 0, rng.uniform(-1e-3, 1e-3, n),                 # near tangent
+          np.where(kind == 1, rng.choice([-1e-7, -1e-9, 0.0, 1e-9, 1e-7], n),  # tangent to float32 resolution
+          np.where(kind == 2, rng.uniform(-1.0, 0.5, n), rng.uniform(-1.0, 3.0, n))))
+    target = c + perp * (r * (1.0 + eps))[:, None]
+    d = target - o
+    # kind 3: origin exactly on the surface (what every scattered ray looks like), random direction
+    on = kind == 3
+    n_on = int(on.sum())
+    if n_on:
+        nrm = _unit(rng, n_on)
+        o[on] = c[on] + nrm * r[on, None]
+        d[on] = nrm + _unit(rng, n_on) * rng.choice([1.0, 0.999999, 1.000001], (n_on, 1))   # lambertian: may be ~0
+    # kind 4: backwards (sphere behind the origin) -- must be dropped often, kept never required
+    back = kind == 4
+    d[back] = -d[back]
+    d *= rng.choice([1.0, 1e-3, 37.0, 1e-6], size=(n, 1))
+    return o, d, c0, dc, moving, f, r * r
+
+
+@pytest.mark.parametrize("scale,r_lo,r_hi,origin", [
+    (12.0, 0.2, 0.2, (0.0, 0.0, 0.0)),          # random_scene-like
+    (12.0, 0.05, 1.0, (3.0, 1.0, -2.0)),
+    (300.0, 0.01, 5.0, (1000.0, -2000.0, 500.0)),   # far from the world origin; P recentres
+    (2e4, 1.0, 100.0, (0.0, 0.0, 0.0)),
+    (0.01, 1e-4, 1e-3, (0.0, 0.0, 0.0)),         # tiny scene
+])
+def test_filter_never_drops_a_needed_object(tor, scale, r_lo, r_hi, origin):
+    rng = np.random.default_rng(int(scale * 1000) + 7)
+    origin = np.asarray(origin, dtype=np.float64)
+    n = 400_000
+    o, d, c0, dc, moving, f, r2 = _cases(rng, n, scale, r_lo, r_hi, origin)
+    keep, need = tor.selftest_filter32(o, d, c0, dc, moving, f, r2, origin)
+    missed = np.flatnonzero((need != 0) & (keep == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
+    # (how little it over-keeps on a realistic distribution is test_filter_drops_the_obvious; these cases sit
+    # on the decision boundary on purpose)
+    assert np.count_nonzero(need) > n // 10     # the cases do exercise the keep side
+
+
+def test_filter_degenerate_rays_keep_everything(tor):
+    """a = |d|^2 outside [2^-40, 2^40], non-finite origins or f: the lane keeps every object (float64 decides)."""
+    n = 6
+    o = np.zeros((n, 3)); d = np.tile([0.0, 0.0, 1.0], (n, 1))
+    c0 = np.tile([0.0, 0.0, -5.0], (n, 1)); dc = np.zeros((n, 3)); moving = np.zeros(n, dtype=np.int32)
+    f = np.zeros(n); r2 = np.full(n, 0.25)
+    d[0] = 0.0                      # zero direction
+    d[1] = [1e-30, 0, 0]
+    d[2] = [1e30, 0, 0]
+    o[3] = [np.inf, 0, 0]
+    o[4] = [np.nan, 0, 0]
+    moving[5] = 1; f[5] = 1e30      # time far outside the object's interval
+    keep, _ = tor.selftest_filter32(o, d, c0, dc, moving, f, r2, np.zeros(3))
+    assert keep.tolist() == [1] * n
+
+
+def test_filter_drops_the_obvious(tor):
+    """Far misses and spheres behind the ray are dropped (the point of the exercise)."""
+    rng = np.random.default_rng(5)
+    n = 100_000
+    c0 = rng.uniform(-10, 10, size=(n, 3))
+    o = np.tile([13.0, 2.0, 3.0], (n, 1))
+    d = _unit(rng, n)
+    keep, need = tor.selftest_filter32(o, d, c0, np.zeros((n, 3)), np.zeros(n, dtype=np.int32), np.zeros(n),
+                                       np.full(n, 0.04), np.zeros(3))
+    assert np.all(keep[need != 0] == 1)
+    assert np.count_nonzero(keep) < 1.05 * np.count_nonzero(need) + 50
+    assert np.count_nonzero(keep) < 0.01 * n

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "tor_kernels.hpp"
+#include "tor_filter32.hpp"
 #include "tor_scene.hpp"
 
 // ---- layout guards: the structs must match what Nim's C backend emits --------
@@ -672,6 +673,36 @@ int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_hi, int6
     for (int c = 0; c < 6; ++c) super_boxes[6 * sidx + c] = bnd[8 * (size_t)(n_bnd_p + 1 + sidx) + c];
   if (two_level_out) *two_level_out = acc.two_level ? 1 : 0;
   return (int)n_blocks;
+}
+
+// TOR_ACCEL_F32 self test (host build of tor_filter32.hpp, no device needed): ray i against sphere i.
+// keep[i] = the float32 pre-filter's decision; need[i] = the float64 condition it must never miss,
+// D > 0 and (half_b < 0 or c < 0) evaluated as spheres.nim:30-33 does (bit 1: a root > 0.001 exists).
+int tor_selftest_filter32_host(int64_t n, const double* o, const double* d, const double* c0, const double* dc,
+                               const int32_t* moving, const double* f, const double* r2, const double* origin,
+                               int32_t* keep, int32_t* need) {
+  if (n < 0 || !o || !d || !c0 || !dc || !moving || !f || !r2 || !origin || !keep || !need)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_filter32_host: bad argument");
+  for (int64_t i = 0; i < n; ++i) {
+    const double* oo = o + 3 * i; const double* dd = d + 3 * i; const double* cc0 = c0 + 3 * i; const double* dcc = dc + 3 * i;
+    const bool mv = moving[i] != 0;
+    keep[i] = (int32_t)tor::filter_one(oo, dd, cc0, dcc, mv, f[i], r2[i], origin);
+    double c[3] = {cc0[0], cc0[1], cc0[2]};
+    if (mv) for (int k = 0; k < 3; ++k) c[k] = cc0[k] + dcc[k] * f[i];  // moving_spheres.nim:43
+    const double ocx = oo[0] - c[0], ocy = oo[1] - c[1], ocz = oo[2] - c[2];
+    const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+    const double hb = ocx * dd[0] + ocy * dd[1] + ocz * dd[2];
+    const double cq = (ocx * ocx + ocy * ocy + ocz * ocz) - r2[i];
+    const double disc = hb * hb - a * cq;
+    int32_t nd = (disc > 0.0 && (hb < 0.0 || cq < 0.0)) ? 1 : 0;
+    if (disc > 0.0) {
+      const double root = std::sqrt(disc);
+      const double s0 = (-hb - root) / a, s1 = (-hb + root) / a;
+      if ((0.001 < s0 && s0 < INFINITY) || (0.001 < s1 && s1 < INFINITY)) nd |= 2;
+    }
+    need[i] = nd;
+  }
+  return TOR_OK;
 }
 
 // ---- self tests -----------------------------------------------------------------------------

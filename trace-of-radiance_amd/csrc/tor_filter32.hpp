@@ -1,0 +1,161 @@
+// tor_filter32.hpp -- TOR_ACCEL_F32: a conservative float32 pre-filter in front of the float64 sphere test.
+//
+// The reference decides ray x sphere with the float64 discriminant  D = hb*hb - a*c  (spheres.nim:30-33,
+// moving_spheres.nim:46-51) and accepts a root only if it is > 0.001, which needs  D > 0  and  (hb < 0 or
+// c < 0).  The hot loop only has to find the few objects for which that CAN hold; the exact float64 hit
+// (roots, closest-hit update) is recomputed for those anyway.  So the loop may run in any arithmetic as long
+// as it never drops an object the float64 test would keep.  This header does it in packed float32
+// (v_pk_fma_f32 / v_pk_add_f32: two objects per instruction, object records through the scalar data path),
+// with the rounding error of the float32 evaluation bounded a priori and folded into the comparison.
+//
+// Error bound (u = 2^-24, all operations round to nearest, no overflow/underflow -- the caller guards the
+// ranges; hats are float32 values, capitals the real-number values of the float64 inputs):
+//   coordinates relative to an origin P near the scene:  o^ = fl(o - P), c^ = fl(c0 - P) [+ fl(dc) * f^]
+//   Lambda := |o-P| + 3.1 Mc + |OC|,  Mc := |c0-P| + |f| |dc|          (Euclidean norms)
+//   |oc^ - OC|           <= 1.001 u Lambda                              (3 roundings of inputs, 1 of the subtraction)
+//   |hb^ - HB|           <= 5.02 u |d| Lambda                           (3 products, 3 roundings)
+//   |c^  - C |           <= u (2.01 |OC| Lambda + 3.02 |OC|^2 + 4.02 r^2) + u^2 Lambda^2
+// The filter evaluates, per object,
+//   hb'' = hb^ - mbl          mbl >= 5.1 u |d| (2|o-P| + 4.1 max Mc)   =>  HB < 0  implies  hb'' < 0 and |hb''| >= |HB|
+//   y    = m - a^ c^          m   >= 1.002 u A (9.81 c^ + 15.84 r^2 + 7.25 Mc^2 + 0.754 |o-P|^2)
+//   D''  = hb''^2 + y
+// and keeps the object iff  D'' >= 0  and  (hb'' < 0  or  y >= 0)   [sign bits only].
+//   * C < 0           =>  c^ < E_c <= m / a^  =>  y >= 0, and then D'' >= 0 as a sum of non-negatives;
+//   * HB < 0, D > 0   =>  hb''^2 + y >= HB^2 - A C + (m - error terms) >= D > 0.
+// (2.01 |OC| Lambda <= 4.02 |OC|^2 + 0.2513 Lambda^2 and Lambda^2 <= 3 (|o-P|^2 + 9.61 Mc^2 + |OC|^2) turn the
+// bound into the linear form above; |OC|^2 = C + r^2.)  The constants below carry a further 5-8 % of slack,
+// which also covers the roundings of the margin arithmetic itself and the 2^-50-relative gap between the
+// float64-computed D, HB, C and their real values.  For |o-P|, |c-P| ~ 15 and r = 0.2 (random_scene) the
+// margins widen a sphere by < 1 % -- the filter keeps ~2 % more candidates than the exact sign test.
+//
+// tests/test_filter32.py drives filter_one() (host build of this header) with random and adversarial
+// (tangent, origin on the surface, far-away, tiny direction) ray/sphere pairs and checks it never drops an
+// object the float64 test keeps; the GPU parity tests then compare whole canvases bit for bit.
+#pragma once
+
+#include "tor_math.hpp"
+
+namespace tor {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+TOR_HD f2v splat2(float x) { return (f2v){x, x}; }
+TOR_HD f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+constexpr float kU32 = 0x1p-24f;
+constexpr float kF32Gain = 10.5f * kU32;  // >= 1.002 * 9.81 u, + slack
+constexpr float kF32Mbl = 5.5f * kU32;    // >= 5.1 u, + slack
+constexpr float kF32KRo = 0.08f;          // >= 0.754 / 9.81
+constexpr float kF32KDc = 1.5f;           // >= 2 * 7.25 / 9.81   (Mc^2 <= 2 |c0-P|^2 + 2 f^2 |dc|^2)
+constexpr double kF32KR2 = 1.65;          // >= 15.84 / 9.81      (host: per-object constant k)
+constexpr double kF32KMc = 0.75;          // >= 7.25 / 9.81
+constexpr float kF32Lim = 0x1p20f;        // |c0-P|, |dc|, |f| admitted by the guards
+constexpr float kF32PadR2 = -1e30f;       // r^2 of a padding record: c^ ~ 1e30, y < 0, D'' < 0
+
+// per query
+struct RayF32 {
+  float ox, oy, oz, dx, dy, dz;  // o - P and d, rounded to float32
+  float na, g;                   // -a and the margin gain * a
+  float ro, ro2, sa;             // |o-P|, |o-P|^2, sqrt(a)
+  unsigned wild;                 // 0xff: ranges not guaranteed -> the lane keeps every object
+};
+
+TOR_HD RayF32 make_ray_f32(double ox, double oy, double oz, double dx, double dy, double dz, double a,
+                           double px, double py, double pz) {
+  RayF32 r;
+  r.ox = (float)(ox - px); r.oy = (float)(oy - py); r.oz = (float)(oz - pz);
+  r.dx = (float)dx; r.dy = (float)dy; r.dz = (float)dz;
+  const float fa = (float)a;
+  r.na = -fa;
+  r.g = kF32Gain * fa;
+  r.ro2 = __builtin_fmaf(r.oz, r.oz, __builtin_fmaf(r.oy, r.oy, r.ox * r.ox));
+  r.ro = __builtin_sqrtf(r.ro2);
+  r.sa = __builtin_sqrtf(fa);
+  const bool sane = (fa >= 0x1p-40f) && (fa <= 0x1p40f) && (r.ro2 <= 0x1p40f);  // false for NaN
+  r.wild = sane ? 0u : 0xffu;
+  return r;
+}
+
+// per query and segment (a segment = objects sharing (time0, time1); f = (time - time0)/(time1 - time0),
+// 0 for static spheres; mc0max / dcmax = max |c0-P| / max |dc| over the segment, rounded up)
+struct SegF32 {
+  f2v nmbl, gk, f;
+  unsigned wild;
+};
+
+TOR_HD SegF32 make_seg_f32(const RayF32& r, double f64, float mc0max, float dcmax) {
+  SegF32 s;
+  const float f = (float)f64;
+  const float af = __builtin_fabsf(f);
+  s.wild = (af <= kF32Lim) ? r.wild : 0xffu;  // NaN -> wild
+  const float mcl = mc0max + af * dcmax;
+  s.nmbl = splat2(-(kF32Mbl * r.sa * (2.0f * r.ro + 4.2f * mcl)));
+  s.gk = splat2(r.g * (kF32KRo * r.ro2 + kF32KDc * ((f * f) * (dcmax * dcmax))));
+  s.f = splat2(f);
+  return s;
+}
+
+// Two objects (the halves of the vectors) against one ray; pushes their keep-bits into m (first object
+// ends up in the higher bit, as the float64 loops do).  k = 1.65 r^2 + 0.75 (1|2) |c0-P|^2 per object.
+TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v cx, f2v cy, f2v cz, f2v r2, f2v k,
+                              unsigned m) {
+  const f2v ocx = splat2(r.ox) - cx, ocy = splat2(r.oy) - cy, ocz = splat2(r.oz) - cz;
+  const f2v hb = fma2(ocz, splat2(r.dz), fma2(ocy, splat2(r.dy), fma2(ocx, splat2(r.dx), s.nmbl)));
+  const f2v cc = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, -r2)));
+  const f2v mm = fma2(splat2(r.g), cc + k, s.gk);
+  const f2v y = fma2(splat2(r.na), cc, mm);
+  const f2v dd = fma2(hb, hb, y);
+  // keep = (sign(hb) | ~sign(y)) & ~sign(D''): one v_bitop3_b32 (truth table 0x51), bit 31
+  unsigned w0, w1;
+#if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
+  w0 = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(unsigned, hb.x), __builtin_bit_cast(unsigned, y.x),
+                                   __builtin_bit_cast(unsigned, dd.x), 0x51);
+  w1 = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(unsigned, hb.y), __builtin_bit_cast(unsigned, y.y),
+                                   __builtin_bit_cast(unsigned, dd.y), 0x51);
+  m = __builtin_amdgcn_alignbit(m, w0, 31);
+  m = __builtin_amdgcn_alignbit(m, w1, 31);
+#else
+  w0 = (__builtin_bit_cast(unsigned, hb.x) | ~__builtin_bit_cast(unsigned, y.x)) & ~__builtin_bit_cast(unsigned, dd.x);
+  w1 = (__builtin_bit_cast(unsigned, hb.y) | ~__builtin_bit_cast(unsigned, y.y)) & ~__builtin_bit_cast(unsigned, dd.y);
+  m = (m << 1) | (w0 >> 31);
+  m = (m << 1) | (w1 >> 31);
+#endif
+  return m;
+}
+
+// Host-side per-object constant k (rounded up) and eligibility; used by tor_scene.cpp and the self test.
+inline bool f32_eligible(double mc0, double dcn, double r2) {
+  return std::isfinite(mc0) && std::isfinite(dcn) && std::isfinite(r2) && mc0 <= (double)kF32Lim * 0.5 &&
+         dcn <= (double)kF32Lim * 0.5 && r2 >= 0x1p-40 && r2 <= 0x1p40;
+}
+inline float f32_round_up(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+inline float f32_object_k(double mc0, double r2, bool moving) {
+  return f32_round_up(1.001 * (kF32KR2 * r2 + kF32KMc * (moving ? 2.0 : 1.0) * mc0 * mc0));
+}
+
+// One ray against one object through the same code path as the kernel (both vector halves carry the object).
+// Returns the keep bit.
+inline unsigned filter_one(const double o[3], const double d[3], const double c0[3], const double dc[3],
+                           bool moving, double f64, double r2, const double P[3]) {
+  const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const RayF32 r = make_ray_f32(o[0], o[1], o[2], d[0], d[1], d[2], a, P[0], P[1], P[2]);
+  const double q[3] = {c0[0] - P[0], c0[1] - P[1], c0[2] - P[2]};
+  const double mc0 = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  const double dcn = moving ? std::sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]) : 0.0;
+  if (!f32_eligible(mc0, dcn, r2)) return 1u;  // such an object stays on the float64 path
+  const SegF32 s = make_seg_f32(r, moving ? f64 : 0.0, f32_round_up(mc0), f32_round_up(dcn));
+  f2v cx = splat2((float)q[0]), cy = splat2((float)q[1]), cz = splat2((float)q[2]);
+  if (moving) {
+    cx = fma2(splat2((float)dc[0]), s.f, cx);
+    cy = fma2(splat2((float)dc[1]), s.f, cy);
+    cz = fma2(splat2((float)dc[2]), s.f, cz);
+  }
+  unsigned m = filter_pair32(r, s, cx, cy, cz, splat2((float)r2), splat2(f32_object_k(mc0, r2, moving)), 0u);
+  return ((m | s.wild) & 1u);
+}
+
+}  // namespace tor
