@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seeding", choices=["sample", "pixel"], default="sample")
     ap.add_argument("--arith", choices=["strict", "fused"], default="strict")
-    ap.add_argument("--accel", choices=["none", "blocks"], default="none",
+    ap.add_argument("--accel", choices=["none", "blocks", "f32", "blocks+f32"], default="none",
                     help="none: the reference's brute-force closest hit (the metric's algorithm); blocks: exact block culling (SURVEY 8 f4)")
     ap.add_argument("--row-tile", type=int, default=1,
                     help="rows per shard tile; 1 = row-cyclic: every rank gets nrows/N rows (+-1) of statistically equal cost")
@@ -136,7 +136,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
         if f % max(world, 1) == (rank if world > 1 else 0):
             frames.append((cam, scene))
     ctx = tor.Context(local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0)
-    opt = tor.make_options(seeding=seeding, arith=arith, accel=tor.ACCEL_BLOCKS if args.accel == "blocks" else tor.ACCEL_NONE)
+    opt = tor.make_options(seeding=seeding, arith=arith, accel=ACCEL_BITS[args.accel])
     buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -178,6 +178,9 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+ACCEL_BITS = {"none": 0, "blocks": 1, "f32": 2, "blocks+f32": 3}
+
+
 def main():
     args = parse_args()
     import torch
@@ -216,7 +219,7 @@ def main():
     ctx.upload(scene.list())
     opt = tor.make_options(seeding=seeding, arith=arith, shard_index=rank if world > 1 else 0,
                            shard_count=max(world, 1), row_tile=args.row_tile,
-                           accel=tor.ACCEL_BLOCKS if args.accel == "blocks" else tor.ACCEL_NONE)
+                           accel=ACCEL_BITS[args.accel])
     tdist = importlib.import_module("trace-of-radiance_amd.distributed")
     plan = tdist.ShardPlan(H, args.row_tile, max(world, 1))
     frame = tdist.DistributedFrame(plan, W, rank if world > 1 else 0, torch.device("cuda"))
@@ -304,22 +307,27 @@ def main():
         if verified is not None:
             result["gathered_frame_identical_to_single_process"] = verified
     if rank == 0 and world == 1 and args.accel == "none" and not args.no_accel_leg:
-        # secondary leg (never the metric's value): the same frame with TOR_ACCEL_BLOCKS -- exact block
-        # culling, bit-identical canvas (tests/test_gpu_parity.py::test_block_culling_never_changes_a_pixel)
-        opt2 = tor.make_options(seeding=seeding, arith=arith, row_tile=args.row_tile, accel=tor.ACCEL_BLOCKS)
+        # secondary legs (never the metric's value): the same frame with the exact accelerations -- bit-identical
+        # canvas (tests/test_gpu_parity.py::test_block_culling_never_changes_a_pixel), checked here again
         ref_frame = frame.shard.clone()
-        ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
-        torch.cuda.synchronize()
-        same = bool(torch.equal(ref_frame, frame.shard))
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
+        notes = {"f32": "every ray x every object, through the conservative packed-float32 pre-filter first "
+                        "(tor_filter32.hpp); kept objects get the reference's float64 test",
+                 "blocks": "SURVEY 8 f4: spatial blocks of 8 objects behind conservative boxes",
+                 "blocks+f32": "both"}
+        for name in ("f32", "blocks", "blocks+f32"):
+            opt2 = tor.make_options(seeding=seeding, arith=arith, row_tile=args.row_tile, accel=ACCEL_BITS[name])
             ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        result["accel_blocks"] = {"value": round(total_samples * args.steps / dt2 / 1e6, 2), "unit": "Msamples/s",
-                                  "ms_per_step": round(dt2 / args.steps * 1e3, 3), "canvas_identical_to_brute_force": same,
-                                  "note": "SURVEY 8 f4: spatial blocks of 8 objects behind conservative boxes; the metric's "
-                                          "value above is the reference's brute-force closest hit"}
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref_frame, frame.shard))
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            result["accel_" + name.replace("+", "_")] = {
+                "value": round(total_samples * args.steps / dt2 / 1e6, 2), "unit": "Msamples/s",
+                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "canvas_identical_to_brute_force": same,
+                "note": notes[name] + "; the metric's value above is the reference's float64 brute-force closest hit"}
     if args.stats and rank == 0:
         ctx.set_stats(True)
         step()

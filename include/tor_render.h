@@ -113,11 +113,16 @@ enum {
   TOR_ARITH_FUSED = 1   /* same formulas with explicit fma(); throughput variant          */
 };
 
-/* Candidate culling.  Never changes a pixel: closest hit is order independent. */
+/* Exact accelerations of the closest-hit query; a bit mask.  They never change a pixel:
+ * closest hit is order independent and every kept object goes through the reference's float64 test. */
 enum {
-  TOR_ACCEL_NONE = 0,   /* the reference's algorithm: every ray against every object (default)      */
-  TOR_ACCEL_BLOCKS = 1  /* objects in spatial blocks of 8 with conservative bounding spheres; a ray  */
-                        /* only expands the blocks whose bound it can touch                          */
+  TOR_ACCEL_NONE = 0,   /* the reference's algorithm and arithmetic: every ray against every object in
+                           float64 (default)                                                          */
+  TOR_ACCEL_BLOCKS = 1, /* objects in spatial blocks of 8 inside conservative boxes; a ray only looks
+                           into the blocks whose box it can touch                                     */
+  TOR_ACCEL_F32 = 2     /* still every ray against every object, but first through a conservative
+                           packed-float32 discriminant with an a-priori error margin; only the objects
+                           it cannot rule out get the float64 test                                    */
 };
 
 typedef struct TorOptions {
@@ -129,7 +134,7 @@ typedef struct TorOptions {
    * tiles of row_tile rows; tile t is rendered by shard (t mod shard_count).  The shard's
    * rows are written compactly, in increasing row order.  shard_count <= 1: whole image. */
   int32_t shard_index, shard_count, row_tile;
-  int32_t accel;        /* TOR_ACCEL_* (default TOR_ACCEL_NONE) */
+  int32_t accel;        /* TOR_ACCEL_* bits (default TOR_ACCEL_NONE) */
 } TorOptions;
 
 /* Status codes (the reference's render() returns void and has no error path; this ABI
@@ -283,6 +288,12 @@ TOR_API int tor_canvas_to_rgb8(const TorCanvas* canvas, uint8_t* out);
 TOR_API int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_hi, int64_t* slot_object,
                                    int64_t slot_cap, double* block_boxes, double* super_boxes, int64_t box_cap,
                                    int32_t* two_level_out);
+
+/* TOR_ACCEL_F32 over a whole scene on the HOST: builds the layout tor_scene_upload builds and walks its float32
+ * segments for each ray (origin o, direction d, time) exactly as the kernel does.
+ * keep[ray * world.len + object] = 1 kept, 0 dropped, 2 object stays on the float64 loop. */
+TOR_API int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d,
+                                     const double* time, int8_t* keep);
 
 /* TOR_ACCEL_F32 self test on the HOST (same source as the kernel's pre-filter): ray i against sphere i with
  * centre c0 + dc * f (moving != 0) or c0.  keep[i] = pre-filter keeps the object; need[i] bit 0 = the

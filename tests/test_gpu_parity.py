@@ -128,26 +128,31 @@ def test_high_spp_sums_stay_exact(tor, oracle, ref_scene, ref_camera):
     _assert_parity(cv.pixels, want)
 
 
-def test_block_culling_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
-    """TOR_ACCEL_BLOCKS: spatial blocks of 8 objects behind conservative bounding
-    spheres.  Closest hit is order independent (hittables_lists.nim:48-55), so the canvases must
-    be bit-identical to the brute-force path and to the oracle -- random_scene (395 moving + 90
-    static spheres), an animated frame (1601 static spheres), and a scene with several time
+ACCELS = (1, 2, 3)   # TOR_ACCEL_BLOCKS, TOR_ACCEL_F32, both
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_block_culling_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera, accel):
+    """TOR_ACCEL_BLOCKS (spatial blocks of 8 objects behind conservative boxes) and
+    TOR_ACCEL_F32 (conservative packed-float32 pre-filter in front of the float64 test).  Closest hit is
+    order independent (hittables_lists.nim:48-55) and every kept object goes through the float64 test, so
+    the canvases must be bit-identical to the brute-force path and to the oracle -- random_scene (395
+    moving + 90 static spheres), an animated frame (1601 static spheres), and a scene with several time
     groups, general movers, overlapping, duplicate and negative-radius spheres."""
     objs, _ = ref_scene
     scene, cam = tor.random_scene(0xFACADE), tor.camera()
     for seeding in (tor.SEED_PIXEL, tor.SEED_SAMPLE):
         for arith in (0, 1):
             base = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, arith=arith)
-            acc = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, arith=arith, accel=tor.ACCEL_BLOCKS)
+            acc = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, arith=arith, accel=accel)
             assert np.array_equal(acc.pixels, base.pixels), (seeding, arith)
         want = oracle.render(36, 64, 16, ref_camera, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels
-        acc = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, accel=tor.ACCEL_BLOCKS)
+        acc = _render(tor, scene, cam, 36, 64, 16, seeding=seeding, accel=accel)
         _assert_parity(acc.pixels, want)
     # animated frame
     cam2, scene2, _ = next(iter(tor.Animation(27, 48, 0.005, 0.3, 2.0).scenes(6)))
     base = _render(tor, scene2, cam2, 27, 48, 8, seeding=tor.SEED_SAMPLE)
-    acc = _render(tor, scene2, cam2, 27, 48, 8, seeding=tor.SEED_SAMPLE, accel=tor.ACCEL_BLOCKS)
+    acc = _render(tor, scene2, cam2, 27, 48, 8, seeding=tor.SEED_SAMPLE, accel=accel)
     assert np.array_equal(acc.pixels, base.pixels)
     # synthetic: 300 objects, 3 time groups (one general mover group), duplicates, hollow spheres, big ones
     rng = np.random.default_rng(5)
@@ -171,7 +176,7 @@ def test_block_culling_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera)
     scene3, recs3 = _custom_scene(tor, oracle, recs)
     for seeding in (0, 1):
         base = _render(tor, scene3, cam, 30, 52, 12, seeding=seeding)
-        acc = _render(tor, scene3, cam, 30, 52, 12, seeding=seeding, accel=tor.ACCEL_BLOCKS)
+        acc = _render(tor, scene3, cam, 30, 52, 12, seeding=seeding, accel=accel)
         assert np.array_equal(acc.pixels, base.pixels), seeding
         want = oracle.render(30, 52, 12, ref_camera, recs3, seeding=seeding, math=1, arith=0, accum=seeding).pixels
         _assert_parity(acc.pixels, want)
@@ -229,7 +234,7 @@ def test_edge_cases_match_oracle(tor, oracle, ref_camera):
     big = [[0, 13, 2, 3, 13, 2, 3, 0, 1, 5.0 + 0.01 * i, 2, 0, 0, 0, 0, 1.5] for i in range(300)]
     scene2, recs2 = _custom_scene(tor, oracle, big)
     want = oracle.render(6, 6, 2, ref_camera, recs2, max_depth=8, seeding=1, math=1, accum=1).pixels
-    for accel in (tor.ACCEL_NONE, tor.ACCEL_BLOCKS):
+    for accel in (0, 1, 2, 3):
         cv = _render(tor, scene2, cam, 6, 6, 2, 8, seeding=1, accel=accel)
         _assert_parity(cv.pixels, want)
 
@@ -396,8 +401,9 @@ def test_block_culling_randomised_scenes(tor, oracle):
         h, w, spp = 20, 34, 6
         seeding = trial % 2
         base = _render(tor, scene, cam, h, w, spp, 12, seeding=seeding)
-        acc = _render(tor, scene, cam, h, w, spp, 12, seeding=seeding, accel=tor.ACCEL_BLOCKS)
-        assert np.array_equal(acc.pixels, base.pixels), f"trial {trial}: culling changed {(acc.pixels != base.pixels).sum()} values"
+        for accel in ACCELS:
+            acc = _render(tor, scene, cam, h, w, spp, 12, seeding=seeding, accel=accel)
+            assert np.array_equal(acc.pixels, base.pixels), f"trial {trial} accel {accel}: changed {(acc.pixels != base.pixels).sum()} values"
         ocam = oracle.camera(look_from=ck["look_from"], look_at=ck["look_at"], vfov=ck["vertical_field_of_view"],
                              aperture=ck["aperture"], focus_dist=ck["focus_distance"], shutter_open=shutter[0],
                              shutter_close=shutter[1])
@@ -417,7 +423,7 @@ def test_full_c2_frame_matches_oracle(tor, oracle, ref_scene, ref_camera):
     ctx.upload(scene.list())
     h, w, spp = 1080, 1920, 100
     want = oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=1, arith=0).pixels
-    for accel in (tor.ACCEL_NONE, tor.ACCEL_BLOCKS):
+    for accel in (0, 1, 2, 3):
         buf = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
         ctx.render_device(cam, h, w, spp, 2.2, 50, tor.make_options(seeding=tor.SEED_PIXEL, accel=accel), buf.data_ptr(),
                           torch.cuda.current_stream().cuda_stream)
@@ -445,3 +451,35 @@ def test_bench_multi_rank_path_on_one_gpu(tor):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["gathered_frame_identical_to_single_process"] is True
     assert d["scaling"] == "weak" and "8 spp (4 per GPU)" in d["config"]["workload"] and d["value"] > 0
+
+
+def test_f32_filter_extreme_scenes(tor):
+    """TOR_ACCEL_F32 where float32 is weakest: the whole scene 5-8 thousand units away from the world origin
+    (the filter works relative to its own origin), a scene three orders of magnitude smaller, and one so
+    spread out that part of the objects fall outside the filter's range and stay on the float64 loop.
+    Bit-identical canvases in every case."""
+    rng = np.random.default_rng(77)
+    for case in range(3):
+        recs = _random_records(rng, 260, 6.0, with_big=case != 1)
+        shift = np.zeros(3)
+        scale = 1.0
+        if case == 0:
+            shift = np.array([5000.0, -3000.0, 8000.0])
+        elif case == 1:
+            scale = 1e-3
+        else:
+            far = rng.random(len(recs)) < 0.3           # a third of the objects 100x farther out
+            recs[far, 1:4] *= 100.0
+            recs[far, 4:7] *= 100.0
+        recs[:, 1:4] = recs[:, 1:4] * scale + shift
+        recs[:, 4:7] = recs[:, 4:7] * scale + shift
+        recs[:, 9] *= scale
+        scene = tor.Scene.from_records(recs)
+        cam = tor.camera(look_from=tuple(np.array([11.0, 4.0, 7.0]) * scale + shift), look_at=tuple(np.array([0.0, 0.6, 0.0]) * scale + shift),
+                         vertical_field_of_view=40.0, aperture=0.05 * scale, focus_distance=12.0 * scale)
+        for seeding in (0, 1):
+            base = _render(tor, scene, cam, 24, 40, 8, 12, seeding=seeding)
+            for accel in (2, 3):
+                acc = _render(tor, scene, cam, 24, 40, 8, 12, seeding=seeding, accel=accel)
+                assert np.array_equal(acc.pixels, base.pixels), (case, seeding, accel, int((acc.pixels != base.pixels).sum()))
+        assert base.pixels.std() > 0.01          # the frames are not trivially empty

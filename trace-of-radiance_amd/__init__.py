@@ -29,7 +29,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 SEED_PIXEL, SEED_SAMPLE = 0, 1
 ARITH_STRICT, ARITH_FUSED = 0, 1
-ACCEL_NONE, ACCEL_BLOCKS = 0, 1
+ACCEL_NONE, ACCEL_BLOCKS, ACCEL_F32 = 0, 1, 2
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SPHERE, MOVING_SPHERE = 0, 1
 
@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
-    "tor_encode_frame_device", "tor_render_frame_h264", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_encode_frame_device", "tor_render_frame_h264", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -201,6 +201,7 @@ def lib():
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32)]
     L.tor_selftest_filter32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
         [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2
+    L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -538,6 +539,17 @@ def selftest_filter32(o, d, c0, dc, moving, f, r2, origin):
                                             r2.ctypes.data_as(P), origin.ctypes.data_as(P), keep.ctypes.data_as(I),
                                             need.ctypes.data_as(I)))
     return keep, need
+
+
+def debug_filter32_scene(world: HittableList, o, d, time):
+    """keep[n_rays, n_objects] int8 (1 kept, 0 dropped, 2 float64 loop): the TOR_ACCEL_F32 segment walk on the host."""
+    dp = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    o, d, time = dp(o), dp(d), dp(time)
+    keep = np.zeros((len(time), int(world.len)), dtype=np.int8)
+    P = C.POINTER(C.c_double)
+    _check(lib().tor_debug_filter32_scene(world, len(time), o.ctypes.data_as(P), d.ctypes.data_as(P), time.ctypes.data_as(P),
+                                          keep.ctypes.data_as(C.POINTER(C.c_int8))))
+    return keep
 
 
 def selftest_math(op: int, x: np.ndarray, y: np.ndarray | None = None, where: str = "device", device: int = -1):

@@ -77,16 +77,54 @@ struct DeviceBuffer {
 
 }  // namespace
 
+namespace {
+
+// device copy of a tor::HostLayout
+struct DeviceLayout {
+  DeviceBuffer stat, mov, movy, segs, cold, hot32;
+  int n_segs = 0;
+  bool has_f32 = false;
+  hipError_t put(const tor::HostLayout& lay, const std::vector<double>* cold_override = nullptr) {
+    auto up = [](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
+      hipError_t e = b.ensure(bytes > 0 ? bytes : 8);
+      if (e == hipSuccess && bytes > 0) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
+      return e;
+    };
+    const std::vector<double>& c = cold_override ? *cold_override : lay.cold;
+    hipError_t e = up(stat, lay.stat.data(), lay.stat.size() * 8);
+    if (e == hipSuccess) e = up(mov, lay.mov.data(), lay.mov.size() * 8);
+    if (e == hipSuccess) e = up(movy, lay.movy.data(), lay.movy.size() * 8);
+    if (e == hipSuccess) e = up(segs, lay.segs.data(), lay.segs.size() * 8);
+    if (e == hipSuccess) e = up(cold, c.data(), c.size() * 8);
+    if (e == hipSuccess) e = up(hot32, lay.hot32.data(), lay.hot32.size() * 4);
+    n_segs = lay.n_segs;
+    has_f32 = false;
+    for (int s = 0; s < lay.n_segs; ++s) has_f32 = has_f32 || lay.segs[8 * (size_t)s] >= 5.0;
+    return e;
+  }
+  void release() { stat.release(); mov.release(); movy.release(); segs.release(); cold.release(); hot32.release(); }
+};
+
+// device copy of a tor::HostAccel (TOR_ACCEL_BLOCKS): always-list + spatial blocks
+struct DeviceAccel {
+  DeviceLayout always;  // .cold holds always.cold followed by the spatial objects' cold records
+  DeviceBuffer hot, grp;
+  void release() { always.release(); hot.release(); grp.release(); }
+};
+
+}  // namespace
+
 struct TorContext {
   int device = 0;
   int num_cus = 0;
-  // scene
-  DeviceBuffer stat, mov, movy, segs, cold;
-  // TOR_ACCEL_BLOCKS layout: always-list + spatial blocks; bounds travel per launch (ring)
-  tor::HostAccel accel;
-  DeviceBuffer a_stat, a_mov, a_movy, a_segs, a_cold, a_hot, a_grp, bnd_ring;
+  // scene: [0] float64 loops only, [1] with the TOR_ACCEL_F32 segments
+  DeviceLayout flat[2];
+  tor::F32Options f32;
+  // TOR_ACCEL_BLOCKS layouts (same two variants); bounds travel per launch (ring)
+  tor::HostAccel accel[2];
+  DeviceAccel d_accel[2];
+  DeviceBuffer bnd_ring;
   size_t bnd_slot_bytes = 0;
-  int n_segs = 0;
   int64_t n_objects = 0;
   bool scene_ready = false;
   // work
@@ -135,7 +173,7 @@ bool valid_options(const TorOptions* opt, TorOptions& o) {
   }
   if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return false;
   if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return false;
-  if (o.accel != TOR_ACCEL_NONE && o.accel != TOR_ACCEL_BLOCKS) return false;
+  if (o.accel < 0 || o.accel > (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) return false;
   if (o.shard_count < 1) o.shard_count = 1;
   if (o.row_tile < 1) o.row_tile = 1;
   if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
@@ -192,13 +230,11 @@ int tor_context_create(int32_t device, TorContext** out) {
 int tor_context_destroy(TorContext* ctx) {
   if (!ctx) return TOR_OK;
   (void)hipSetDevice(ctx->device);
-  ctx->stat.release();
-  ctx->mov.release();
-  ctx->movy.release();
-  ctx->segs.release();
-  ctx->cold.release();
-  ctx->a_stat.release(); ctx->a_mov.release(); ctx->a_movy.release(); ctx->a_segs.release();
-  ctx->a_cold.release(); ctx->a_hot.release(); ctx->a_grp.release(); ctx->bnd_ring.release();
+  for (int v = 0; v < 2; ++v) {
+    ctx->flat[v].release();
+    ctx->d_accel[v].release();
+  }
+  ctx->bnd_ring.release();
   ctx->counters.release();
   ctx->cam_ring.release();
   ctx->wave_log.release();
@@ -235,34 +271,30 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
   const int64_t n = world.len;
   std::vector<int64_t> ids((size_t)n);
   for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = i;
-  tor::HostLayout lay;
-  std::string err;
-  if (!tor::build_layout(world.objects, ids, lay, err)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: " + err);
-  ctx->n_segs = (int)(n == 0 ? 0 : lay.n_segs);
-  auto put = [](DeviceBuffer& b, const std::vector<double>& v) -> hipError_t {
-    hipError_t e = b.ensure(v.size() * 8);
-    if (e == hipSuccess) e = hipMemcpy(b.ptr, v.data(), v.size() * 8, hipMemcpyHostToDevice);
-    return e;
-  };
-  HIP_TRY(put(ctx->stat, lay.stat));
-  HIP_TRY(put(ctx->mov, lay.mov));
-  HIP_TRY(put(ctx->movy, lay.movy));
-  HIP_TRY(put(ctx->segs, lay.segs));
-  HIP_TRY(put(ctx->cold, lay.cold));
-  // optional second level (TOR_ACCEL_BLOCKS): built now, bounds are computed per render call
-  tor::build_accel(world.objects, n, ctx->accel);
-  if (ctx->accel.available) {
-    HIP_TRY(put(ctx->a_stat, ctx->accel.always.stat));
-    HIP_TRY(put(ctx->a_mov, ctx->accel.always.mov));
-    HIP_TRY(put(ctx->a_movy, ctx->accel.always.movy));
-    HIP_TRY(put(ctx->a_segs, ctx->accel.always.segs));
-    HIP_TRY(put(ctx->a_cold, ctx->accel.cold));
-    HIP_TRY(put(ctx->a_hot, ctx->accel.hot));
-    HIP_TRY(put(ctx->a_grp, ctx->accel.groups));
-    const size_t n_bnd_p = (ctx->accel.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
-    const size_t n_super_p = (n_bnd_p / tor::kPad + tor::kPad - 1) / tor::kPad * tor::kPad;
-    ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * 8;
-    HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
+  ctx->f32 = tor::f32_options_for(world.objects, n);
+  for (int v = 0; v < 2; ++v) {
+    const tor::F32Options* f32 = (v == 1) ? &ctx->f32 : nullptr;
+    tor::HostLayout lay;
+    std::string err;
+    if (!tor::build_layout(world.objects, ids, lay, err, f32)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: " + err);
+    if (n == 0) lay.n_segs = 0;
+    HIP_TRY(ctx->flat[v].put(lay));
+    // optional second level (TOR_ACCEL_BLOCKS): built now, bounds are computed per render call
+    tor::build_accel(world.objects, n, ctx->accel[v], f32);
+    if (ctx->accel[v].available) {
+      auto put = [](DeviceBuffer& b, const std::vector<double>& vec) -> hipError_t {
+        hipError_t e = b.ensure(vec.size() * 8);
+        if (e == hipSuccess) e = hipMemcpy(b.ptr, vec.data(), vec.size() * 8, hipMemcpyHostToDevice);
+        return e;
+      };
+      HIP_TRY(ctx->d_accel[v].always.put(ctx->accel[v].always, &ctx->accel[v].cold));
+      HIP_TRY(put(ctx->d_accel[v].hot, ctx->accel[v].hot));
+      HIP_TRY(put(ctx->d_accel[v].grp, ctx->accel[v].groups));
+      const size_t n_bnd_p = (ctx->accel[v].n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
+      const size_t n_super_p = (n_bnd_p / tor::kPad + tor::kPad - 1) / tor::kPad * tor::kPad;
+      ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * 8;
+      HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
+    }
   }
   ctx->n_objects = n;
   ctx->scene_ready = true;
@@ -315,12 +347,18 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
   tor::KParams p{};
-  p.stat = (const double*)ctx->stat.ptr;
-  p.mov = (const double*)ctx->mov.ptr;
-  p.movy = (const double*)ctx->movy.ptr;
-  p.segs = (const double*)ctx->segs.ptr;
-  p.cold = (const double*)ctx->cold.ptr;
-  p.n_segs = ctx->n_segs;
+  const int v32 = (o.accel & TOR_ACCEL_F32) ? 1 : 0;
+  auto use_layout = [&](const DeviceLayout& L) {
+    p.stat = (const double*)L.stat.ptr;
+    p.mov = (const double*)L.mov.ptr;
+    p.movy = (const double*)L.movy.ptr;
+    p.segs = (const double*)L.segs.ptr;
+    p.cold = (const double*)L.cold.ptr;
+    p.hot32 = L.has_f32 ? (const float*)L.hot32.ptr : nullptr;
+    p.n_segs = L.n_segs;
+  };
+  use_layout(ctx->flat[v32]);
+  for (int k = 0; k < 3; ++k) p.org[k] = ctx->f32.origin[k];
   p.bnd = nullptr;
   p.spatial_base = 0;
   p.shot = nullptr;
@@ -333,33 +371,29 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   std::vector<double>& bnd_host = ctx->bnd_host[slot];
   bool use_accel = false;
   int stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
-  if (o.accel == TOR_ACCEL_BLOCKS && ctx->accel.available) {
+  const tor::HostAccel& hacc = ctx->accel[v32];
+  if ((o.accel & TOR_ACCEL_BLOCKS) && hacc.available) {
     // rays carry the camera's shutter times, or 0 after a metal / dielectric bounce (rays.nim:19)
     const double t_lo = std::fmin(0.0, std::fmin(cam->shutter_open, cam->shutter_close));
     const double t_hi = std::fmax(0.0, std::fmax(cam->shutter_open, cam->shutter_close));
-    use_accel = tor::compute_block_bounds(ctx->accel, t_lo, t_hi, bnd_host);
+    use_accel = tor::compute_block_bounds(hacc, t_lo, t_hi, bnd_host);
   }
   if (use_accel) {
-    p.stat = (const double*)ctx->a_stat.ptr;
-    p.mov = (const double*)ctx->a_mov.ptr;
-    p.movy = (const double*)ctx->a_movy.ptr;
-    p.segs = (const double*)ctx->a_segs.ptr;
-    p.cold = (const double*)ctx->a_cold.ptr;
-    p.n_segs = ctx->accel.always.n_segs;
-    p.spatial_base = (int)ctx->accel.spatial_base;
-    p.shot = (const double*)ctx->a_hot.ptr;
-    p.sgrp = (const double*)ctx->a_grp.ptr;
-    p.shot_stride = ctx->accel.hot_stride;
+    use_layout(ctx->d_accel[v32].always);
+    p.spatial_base = (int)hacc.spatial_base;
+    p.shot = (const double*)ctx->d_accel[v32].hot.ptr;
+    p.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
+    p.shot_stride = hacc.hot_stride;
     // LDS staging of the compact records next to the per-wave queues (18 KB per workgroup, 160 KB per
     // CU): it must fit at this mode's workgroups/CU, else one workgroup fewer, else global loads.
-    const size_t hot_bytes = ctx->accel.hot.size() * 8;
+    const size_t hot_bytes = hacc.hot.size() * 8;
     const char* st = std::getenv("TOR_STAGE_LDS");
     const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
     int& wg = stage_wg;
     wg = 0;
     for (int tryw = ctx->max_blocks_per_cu[o.seeding]; tryw >= 2 && wg == 0; --tryw)
       if (hot_bytes <= hard_cap && hot_bytes + 18432 <= (size_t)(160 * 1024) / (size_t)tryw - 1024) wg = tryw;
-    p.shot_lds_doubles = wg > 0 ? (int)ctx->accel.hot.size() : 0;
+    p.shot_lds_doubles = wg > 0 ? (int)hacc.hot.size() : 0;
   }
   // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
   // kernel variant's register budget follows it
@@ -367,7 +401,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (cap < 1) cap = 4;
   if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
   const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
-  int bpc_eff = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd);
+  int bpc_eff = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd, p.hot32 != nullptr ? 1 : 0);
   if (bpc_eff > cap) bpc_eff = cap;
   const long long resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
@@ -701,6 +735,63 @@ int tor_selftest_filter32_host(int64_t n, const double* o, const double* d, cons
       if ((0.001 < s0 && s0 < INFINITY) || (0.001 < s1 && s1 < INFINITY)) nd |= 2;
     }
     need[i] = nd;
+  }
+  return TOR_OK;
+}
+
+// TOR_ACCEL_F32 on the HOST over a whole scene: builds the same layout tor_scene_upload builds and walks its
+// float32 segments (kinds 5/6/7) for each ray exactly as integrate_kernel does (same records, same
+// tor_filter32.hpp code).  keep[ray * world.len + object] = 1 kept, 0 dropped, 2 object is on the float64
+// loop (not eligible for the filter).  No device needed.
+int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d,
+                             const double* time, int8_t* keep) {
+  if (world.len < 0 || (world.len > 0 && !world.objects) || n_rays < 0 || !o || !d || !time || !keep)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_filter32_scene: bad argument");
+  const tor::F32Options f32 = tor::f32_options_for(world.objects, world.len);
+  std::vector<int64_t> ids((size_t)world.len);
+  for (int64_t i = 0; i < world.len; ++i) ids[(size_t)i] = i;
+  tor::HostLayout lay;
+  std::string err;
+  if (!tor::build_layout(world.objects, ids, lay, err, &f32)) return fail(TOR_ERR_INVALID_ARGUMENT, err);
+  using tor::f2v;
+  for (int64_t r = 0; r < n_rays; ++r) {
+    int8_t* kr = keep + r * world.len;
+    for (int64_t i = 0; i < world.len; ++i) kr[i] = 2;
+    const double* oo = o + 3 * r; const double* dd = d + 3 * r;
+    const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+    const tor::RayF32 r32 = tor::make_ray_f32(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a, f32.origin[0], f32.origin[1], f32.origin[2]);
+    for (int s = 0; s < lay.n_segs; ++s) {
+      const double* sg = &lay.segs[8 * (size_t)s];
+      const int kind = (int)sg[0];
+      if (kind < 5) continue;
+      const int begin = (int)sg[1], count = (int)sg[2], block0 = (int)sg[3];
+      const double f64 = kind == 5 ? 0.0 : (time[r] - sg[4]) / sg[5];
+      const tor::SegF32 s32 = tor::make_seg_f32(r32, f64, (float)sg[6], (float)sg[7]);
+      const int stride = kind == 5 ? 10 : (kind == 6 ? 12 : 16);
+      for (int i = 0; i < count; i += tor::kPad) {
+        unsigned m = 0;
+        for (int j = 0; j < tor::kPad / 2; ++j) {
+          const float* rec = &lay.hot32[(size_t)begin + (size_t)(i / 2 + j) * stride];
+          f2v cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]};
+          if (kind == 6) cy = tor::fma2((f2v){rec[10], rec[11]}, s32.f, cy);
+          if (kind == 7) {
+            cx = tor::fma2((f2v){rec[10], rec[11]}, s32.f, cx);
+            cy = tor::fma2((f2v){rec[12], rec[13]}, s32.f, cy);
+            cz = tor::fma2((f2v){rec[14], rec[15]}, s32.f, cz);
+          }
+          m = tor::filter_pair32(r32, s32, cx, cy, cz, (f2v){rec[6], rec[7]}, (f2v){rec[8], rec[9]}, m);
+        }
+        m |= s32.wild;
+        for (int j = 0; j < tor::kPad; ++j) {
+          const size_t slot = (size_t)(block0 + i / tor::kPad) * tor::kPad + (size_t)j;
+          int64_t orig;
+          std::memcpy(&orig, &lay.cold[16 * slot + 14], 8);
+          const bool padding = lay.cold[16 * slot + 15] < 0.0;
+          const int bit = (m >> (7 - j)) & 1;
+          if (!padding) kr[orig] = (int8_t)bit;
+        }
+      }
+    }
   }
   return TOR_OK;
 }

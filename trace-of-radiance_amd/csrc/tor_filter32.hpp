@@ -105,20 +105,18 @@ TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v cx, f2v cy, 
   const f2v mm = fma2(splat2(r.g), cc + k, s.gk);
   const f2v y = fma2(splat2(r.na), cc, mm);
   const f2v dd = fma2(hb, hb, y);
-  // keep = (sign(hb) | ~sign(y)) & ~sign(D''): one v_bitop3_b32 (truth table 0x51), bit 31
-  unsigned w0, w1;
+  // keep = (sign(hb) | ~sign(y)) & ~sign(D''): one v_bitop3_b32 (truth table 0x51), bit 31.
+  // (Elements are copied to scalars first: __builtin_bit_cast applied directly to `v.y` reads element 0.)
+  const float hb0 = hb.x, hb1 = hb.y, y0 = y.x, y1 = y.y, dd0 = dd.x, dd1 = dd.y;
+  const unsigned bh0 = __builtin_bit_cast(unsigned, hb0), bh1 = __builtin_bit_cast(unsigned, hb1);
+  const unsigned by0 = __builtin_bit_cast(unsigned, y0), by1 = __builtin_bit_cast(unsigned, y1);
+  const unsigned bd0 = __builtin_bit_cast(unsigned, dd0), bd1 = __builtin_bit_cast(unsigned, dd1);
 #if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
-  w0 = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(unsigned, hb.x), __builtin_bit_cast(unsigned, y.x),
-                                   __builtin_bit_cast(unsigned, dd.x), 0x51);
-  w1 = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(unsigned, hb.y), __builtin_bit_cast(unsigned, y.y),
-                                   __builtin_bit_cast(unsigned, dd.y), 0x51);
-  m = __builtin_amdgcn_alignbit(m, w0, 31);
-  m = __builtin_amdgcn_alignbit(m, w1, 31);
+  m = __builtin_amdgcn_alignbit(m, __builtin_amdgcn_bitop3_b32(bh0, by0, bd0, 0x51), 31);
+  m = __builtin_amdgcn_alignbit(m, __builtin_amdgcn_bitop3_b32(bh1, by1, bd1, 0x51), 31);
 #else
-  w0 = (__builtin_bit_cast(unsigned, hb.x) | ~__builtin_bit_cast(unsigned, y.x)) & ~__builtin_bit_cast(unsigned, dd.x);
-  w1 = (__builtin_bit_cast(unsigned, hb.y) | ~__builtin_bit_cast(unsigned, y.y)) & ~__builtin_bit_cast(unsigned, dd.y);
-  m = (m << 1) | (w0 >> 31);
-  m = (m << 1) | (w1 >> 31);
+  m = (m << 1) | (((bh0 | ~by0) & ~bd0) >> 31);
+  m = (m << 1) | (((bh1 | ~by1) & ~bd1) >> 31);
 #endif
   return m;
 }

@@ -53,6 +53,7 @@ namespace tor {
 
 // scalar (constant address space) view of the read-only scene so the compiler emits s_load
 typedef const double __attribute__((address_space(4))) * cdptr;
+typedef const float __attribute__((address_space(4))) * cfptr;
 typedef const double __attribute__((address_space(3))) * ldptr;  // LDS
 typedef const double __attribute__((address_space(1))) * gdptr;  // global
 
@@ -134,7 +135,7 @@ __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
   return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
 }
 
-template <int SEEDING, int ARITH, int WAVES_PER_SIMD>
+template <int SEEDING, int ARITH, int WAVES_PER_SIMD, int F32>
 __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -307,6 +308,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       int best_orig = 0x7fffffff;
       double best_f = 0.0;
 
+      // TOR_ACCEL_F32: the ray in float32, relative to the scene origin (used by segment kinds 5-7 only)
+      RayF32 r32{};
+      if (F32) r32 = make_ray_f32(ox, oy, oz, dx, dy, dz, a_strict, p.org[0], p.org[1], p.org[2]);
+
       int seg = 0;
       int i = 0;
       for (;;) {
@@ -335,6 +340,64 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+            }
+          } else if (F32 && seg_kind >= 5) {
+            // TOR_ACCEL_F32 (tor_filter32.hpp): conservative packed-float32 discriminant, two objects per
+            // instruction; keeps a superset of what the float64 sign filter keeps, the deferred pass below
+            // re-does the kept objects in float64 exactly as the reference.
+            double f64 = 0.0;
+            if (seg_kind != 5) f64 = (time - segs[seg * 8 + 4]) / segs[seg * 8 + 5];  // moving_spheres.nim:42
+            const SegF32 s32 = make_seg_f32(r32, f64, (float)segs[seg * 8 + 6], (float)segs[seg * 8 + 7]);
+            const int stride = (seg_kind == 5) ? 10 : ((seg_kind == 6) ? 12 : 16);
+            cfptr rec = (cfptr)(uintptr_t)p.hot32 + ((long)seg_begin + (long)(i / 2) * stride);
+            if (seg_kind == 5) {
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock / 2; ++j) {
+                  cfptr r = rec + 10 * j;
+                  m = filter_pair32(r32, s32, (f2v){r[0], r[1]}, (f2v){r[2], r[3]}, (f2v){r[4], r[5]},
+                                    (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
+                }
+                rec += 10 * (kBlock / 2);
+                m |= s32.wild;
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
+            } else if (seg_kind == 6) {
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock / 2; ++j) {
+                  cfptr r = rec + 12 * j;
+                  const f2v cy = fma2((f2v){r[10], r[11]}, s32.f, (f2v){r[2], r[3]});
+                  m = filter_pair32(r32, s32, (f2v){r[0], r[1]}, cy, (f2v){r[4], r[5]}, (f2v){r[6], r[7]},
+                                    (f2v){r[8], r[9]}, m);
+                }
+                rec += 12 * (kBlock / 2);
+                m |= s32.wild;
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
+            } else {
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock / 2; ++j) {
+                  cfptr r = rec + 16 * j;
+                  const f2v cx = fma2((f2v){r[10], r[11]}, s32.f, (f2v){r[0], r[1]});
+                  const f2v cy = fma2((f2v){r[12], r[13]}, s32.f, (f2v){r[2], r[3]});
+                  const f2v cz = fma2((f2v){r[14], r[15]}, s32.f, (f2v){r[4], r[5]});
+                  m = filter_pair32(r32, s32, cx, cy, cz, (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
+                }
+                rec += 16 * (kBlock / 2);
+                m |= s32.wild;
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
             }
           } else if (seg_kind == 3 || seg_kind == 4) {
             // TOR_ACCEL_BLOCKS: the records are inflated axis-aligned boxes around spatial blocks of 8
@@ -820,20 +883,33 @@ __global__ void selftest_kernel(int op, const double* x, const double* y, double
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from tor_api.cpp)
 // ---------------------------------------------------------------------------------------
-template <int W>
-static hipError_t launch_integrate_w(const KParams& p, int seeding, int arith, int blocks, hipStream_t stream) {
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
-  dim3 grid((unsigned)blocks), block(kThreads);
-  if (seeding == 0 && arith == 0) hipLaunchKernelGGL((integrate_kernel<0, 0, W>), grid, block, smem, stream, p);
-  else if (seeding == 0 && arith == 1) hipLaunchKernelGGL((integrate_kernel<0, 1, W>), grid, block, smem, stream, p);
-  else if (seeding == 1 && arith == 0) hipLaunchKernelGGL((integrate_kernel<1, 0, W>), grid, block, smem, stream, p);
-  else hipLaunchKernelGGL((integrate_kernel<1, 1, W>), grid, block, smem, stream, p);
-  return hipGetLastError();
+// variant table: [seeding 0|1][arith 0|1][W 2|3|4][f32 0|1]; the TOR_ACCEL_F32 variants exist for the
+// 2- and 3-workgroup launch shapes only
+typedef void (*IntegrateFn)(const KParams);
+static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32) {
+#define TOR_V(S, A, W, F) if (seeding == S && arith == A && w == W && f32 == F) return integrate_kernel<S, A, W, F>;
+  TOR_V(0, 0, 2, 0) TOR_V(0, 1, 2, 0) TOR_V(1, 0, 2, 0) TOR_V(1, 1, 2, 0)
+  TOR_V(0, 0, 3, 0) TOR_V(0, 1, 3, 0) TOR_V(1, 0, 3, 0) TOR_V(1, 1, 3, 0)
+  TOR_V(0, 0, 4, 0) TOR_V(0, 1, 4, 0) TOR_V(1, 0, 4, 0) TOR_V(1, 1, 4, 0)
+  TOR_V(0, 0, 2, 1) TOR_V(0, 1, 2, 1) TOR_V(1, 0, 2, 1) TOR_V(1, 1, 2, 1)
+  TOR_V(0, 0, 3, 1) TOR_V(0, 1, 3, 1) TOR_V(1, 0, 3, 1) TOR_V(1, 1, 3, 1)
+#undef TOR_V
+  return nullptr;
+}
+
+static int clamp_w(int waves_per_simd, int f32) {
+  // register budget follows the launch shape: 2 workgroups/CU -> 256 VGPRs, 3 -> 168, 4 -> 128
+  int w = waves_per_simd <= 2 ? 2 : (waves_per_simd == 3 ? 3 : 4);
+  if (f32 && w > 3) w = 3;
+  return w;
 }
 
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
   const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
-  hipLaunchKernelGGL((integrate_kernel<2, 0, 3>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  if (p.hot32 != nullptr)
+    hipLaunchKernelGGL((integrate_kernel<2, 0, 3, 1>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  else
+    hipLaunchKernelGGL((integrate_kernel<2, 0, 3, 0>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
   return hipGetLastError();
 }
 
@@ -844,29 +920,20 @@ hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles,
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream) {
-  // register budget follows the launch shape: 2 workgroups/CU -> 256 VGPRs, 3 -> 168, 4 -> 128
-  if (waves_per_simd <= 2) return launch_integrate_w<2>(p, seeding, arith, blocks, stream);
-  if (waves_per_simd == 3) return launch_integrate_w<3>(p, seeding, arith, blocks, stream);
-  return launch_integrate_w<4>(p, seeding, arith, blocks, stream);
+  const int f32 = p.hot32 != nullptr ? 1 : 0;
+  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd, f32), f32);
+  if (!fn) return hipErrorInvalidValue;
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  return hipGetLastError();
 }
 
-template <int W>
-static int blocks_per_cu_w(int seeding, int arith) {
+int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd, int f32) {
+  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd, f32), f32);
   const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
   int n = 0;
-  hipError_t e;
-  if (seeding == 0 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 0, W>, kThreads, smem);
-  else if (seeding == 0 && arith == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<0, 1, W>, kThreads, smem);
-  else if (seeding == 1 && arith == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 0, W>, kThreads, smem);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<1, 1, W>, kThreads, smem);
-  if (e != hipSuccess || n < 1) n = 1;
+  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, smem) != hipSuccess || n < 1) n = 1;
   return n;
-}
-
-int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd) {
-  if (waves_per_simd <= 2) return blocks_per_cu_w<2>(seeding, arith);
-  if (waves_per_simd == 3) return blocks_per_cu_w<3>(seeding, arith);
-  return blocks_per_cu_w<4>(seeding, arith);
 }
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {

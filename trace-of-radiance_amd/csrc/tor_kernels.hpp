@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "tor_device.hpp"
+#include "tor_filter32.hpp"
 
 namespace tor {
 
@@ -21,6 +22,10 @@ constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of 
 //          {c0x, c0y, c0z, radius^2, dcy, 0}
 //   segs : 8 float64 per segment {kind (0 static, 1 moving along y only, 2 moving, 3 block bounds), first
 //          record, padded count, (first sorted index)/kPad, time0, time1 - time0, 0, 0}
+//   hot32: TOR_ACCEL_F32 segments (kinds 5 static, 6 moving along y only, 7 moving; segs[1] = float offset,
+//          segs[6] = max |c0 - origin|, segs[7] = max |dc| over the segment): float32 records per PAIR of
+//          objects, interleaved for the packed-float32 filter (tor_filter32.hpp), coordinates relative
+//          to KParams.org:  {cx cx', cy cy', cz cz', r2 r2', k k'} (+ {dcy dcy'} | + {dcx dcx', dcy dcy', dcz dcz'})
 //   cold : 16 float64 per sorted slot {c0 xyz, dc xyz, 1/radius, time0, time1-time0,
 //          albedo xyz, fuzz|refraction_index, flags(bit0 moving, bits 8..15 material kind),
 //          original index, radius^2}; flags/original index are int64 bit patterns.
@@ -30,6 +35,8 @@ struct KParams {
   const double* movy;
   const double* segs;
   const double* cold;
+  const float* hot32;  // TOR_ACCEL_F32 pair records, or null
+  double org[3];       // origin of the float32 coordinates
   const double* bnd;   // TOR_ACCEL_BLOCKS: 8 float64 per block {lo xyz, hi xyz, 0, 0} (segment kind 3), else null
   const double* shot;  // TOR_ACCEL_BLOCKS: 8 float64 per spatial slot {c0 xyz, r^2, dc xyz, time-group id | -1}
   int shot_stride;       // float64 per compact record: 8, or 4 when no spatial object moves
@@ -54,7 +61,7 @@ struct KParams {
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream);
-int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd);
+int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd, int f32);
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
 hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream);
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip

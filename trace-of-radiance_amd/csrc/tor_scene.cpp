@@ -6,6 +6,7 @@
 #include <cstring>
 #include <utility>
 
+#include "tor_filter32.hpp"
 #include "tor_kernels.hpp"
 
 namespace tor {
@@ -63,51 +64,113 @@ bool fill_cold(double* c, const TorHittableVariant& h, int64_t orig) {
 
 // AoS -> SoA.  Objects are partitioned into one static segment and one segment per distinct
 // (time0, time1) pair; closest-hit is order independent (hittables_lists.nim:48-55; ties are broken
-// by the original index carried in the cold record), so the reordering is exact.
-bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& ids, HostLayout& out, std::string& err) {
-  std::vector<int64_t> statics;
-  std::vector<std::pair<std::pair<uint64_t, uint64_t>, std::vector<int64_t>>> groups;
+// by the original index carried in the cold record), so the reordering is exact.  With `f32`, the
+// qualifying objects get a second set of segments (kinds 5/6/7) for the float32 pre-filter.
+namespace {
+
+struct TimeGroup {
+  uint64_t k0, k1;
+  std::vector<int64_t> ids;
+};
+
+void add_to_group(std::vector<TimeGroup>& groups, const TorMovingSphere& s, int64_t i) {
+  uint64_t k0, k1;
+  std::memcpy(&k0, &s.time0, 8);
+  std::memcpy(&k1, &s.time1, 8);
+  for (auto& g : groups)
+    if (g.k0 == k0 && g.k1 == k1) {
+      g.ids.push_back(i);
+      return;
+    }
+  groups.push_back({k0, k1, {i}});
+}
+
+bool group_moves_along_y_only(const TorHittableVariant* objs, const TimeGroup& g) {
+  // every member has center1.x == center0.x and center1.z == center0.z: c0 + f*(c1-c0) leaves x and z untouched, exactly
+  for (int64_t idx : g.ids) {
+    const TorMovingSphere& s = objs[idx].u.moving_sphere;
+    if (!(s.center1.x - s.center0.x == 0.0 && s.center1.z - s.center0.z == 0.0)) return false;
+  }
+  return true;
+}
+
+double norm3(double x, double y, double z) { return std::sqrt(x * x + y * y + z * z); }
+
+}  // namespace
+
+F32Options f32_options_for(const TorHittableVariant* objs, int64_t n) {
+  F32Options o;
+  std::vector<double> ax[3];
+  for (int64_t i = 0; i < n; ++i) {
+    const TorVec3* c = objs[i].kind == TOR_SPHERE ? &objs[i].u.sphere.center
+                       : (objs[i].kind == TOR_MOVING_SPHERE ? &objs[i].u.moving_sphere.center0 : nullptr);
+    if (!c || !std::isfinite(c->x) || !std::isfinite(c->y) || !std::isfinite(c->z)) continue;
+    ax[0].push_back(c->x); ax[1].push_back(c->y); ax[2].push_back(c->z);
+  }
+  if (ax[0].empty()) return o;
+  const size_t mid = ax[0].size() / 2;
+  for (int a = 0; a < 3; ++a) {
+    std::vector<double> t = ax[a];
+    std::nth_element(t.begin(), t.begin() + mid, t.end());
+    o.origin[a] = t[mid];
+  }
+  std::vector<double> dist(ax[0].size());
+  for (size_t k = 0; k < dist.size(); ++k)
+    dist[k] = norm3(ax[0][k] - o.origin[0], ax[1][k] - o.origin[1], ax[2][k] - o.origin[2]);
+  std::nth_element(dist.begin(), dist.begin() + mid, dist.end());
+  o.far_limit = 8.0 * dist[mid];
+  if (!(o.far_limit > 0.0) || !std::isfinite(o.far_limit)) o.far_limit = 0.0;
+  return o;
+}
+
+bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& ids, HostLayout& out, std::string& err,
+                  const F32Options* f32) {
+  std::vector<int64_t> statics, statics32;
+  std::vector<TimeGroup> groups, groups32;
+  auto dist0 = [&](const TorVec3& c) {
+    return norm3(c.x - f32->origin[0], c.y - f32->origin[1], c.z - f32->origin[2]);
+  };
   for (int64_t i : ids) {
     const TorHittableVariant& h = objs[i];
     if (h.kind == TOR_SPHERE) {
-      statics.push_back(i);
+      const TorSphere& s = h.u.sphere;
+      const bool q = f32 && f32_eligible(dist0(s.center), 0.0, s.radius * s.radius) && dist0(s.center) <= f32->far_limit;
+      (q ? statics32 : statics).push_back(i);
     } else if (h.kind == TOR_MOVING_SPHERE) {
-      uint64_t k0, k1;
-      std::memcpy(&k0, &h.u.moving_sphere.time0, 8);
-      std::memcpy(&k1, &h.u.moving_sphere.time1, 8);
-      bool found = false;
-      for (auto& g : groups)
-        if (g.first.first == k0 && g.first.second == k1) {
-          g.second.push_back(i);
-          found = true;
-          break;
-        }
-      if (!found) groups.push_back({{k0, k1}, {i}});
+      const TorMovingSphere& s = h.u.moving_sphere;
+      const double dt = s.time1 - s.time0;
+      const bool q = f32 && std::isfinite(s.time0) && std::isfinite(dt) && dt != 0.0 &&
+                     f32_eligible(dist0(s.center0), norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z),
+                                  s.radius * s.radius) &&
+                     dist0(s.center0) <= f32->far_limit;
+      add_to_group(q ? groups32 : groups, s, i);
     } else {
       err = "unknown HittableVariant kind";
       return false;
     }
   }
   const size_t n_stat_p = padded(statics.size());
-  // a group moves "along y only" when every member has center1.x == center0.x and
-  // center1.z == center0.z: then c0 + f*(c1-c0) leaves x and z untouched, exactly
-  std::vector<char> yonly(groups.size(), 0);
+  std::vector<char> yonly(groups.size(), 0), yonly32(groups32.size(), 0);
   size_t n_mov_p = 0, n_movy_p = 0;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
-    bool y = true;
-    for (int64_t idx : groups[gi].second) {
-      const TorMovingSphere& s = objs[idx].u.moving_sphere;
-      if (!(s.center1.x - s.center0.x == 0.0 && s.center1.z - s.center0.z == 0.0)) { y = false; break; }
-    }
+    const bool y = group_moves_along_y_only(objs, groups[gi]);
     yonly[gi] = y ? 1 : 0;
-    (y ? n_movy_p : n_mov_p) += padded(groups[gi].second.size());
+    (y ? n_movy_p : n_mov_p) += padded(groups[gi].ids.size());
   }
-  out.n_sorted = n_stat_p + n_mov_p + n_movy_p;
+  size_t n32_slots = padded(statics32.size()), n32_floats = padded(statics32.size()) / 2 * 10;
+  for (size_t gi = 0; gi < groups32.size(); ++gi) {
+    const bool y = group_moves_along_y_only(objs, groups32[gi]);
+    yonly32[gi] = y ? 1 : 0;
+    n32_slots += padded(groups32[gi].ids.size());
+    n32_floats += padded(groups32[gi].ids.size()) / 2 * (y ? 12 : 16);
+  }
+  out.n_sorted = n_stat_p + n_mov_p + n_movy_p + n32_slots;
   // one record of slack behind every hot array: the object loop requests record k+1 while it
   // works on record k
   out.stat.assign(4 * n_stat_p + 8, 0.0);
   out.mov.assign(8 * n_mov_p + 8, 0.0);
   out.movy.assign(6 * n_movy_p + 8, 0.0);
+  out.hot32.assign(n32_floats + 32, 0.0f);
   out.cold.assign(16 * out.n_sorted + 16, 0.0);
   out.segs.clear();
   // padding record: centre 0, radius^2 = -1  => discriminant <= -|d|^2 < 0, never a candidate
@@ -130,14 +193,14 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   size_t mov_rec = 0, movy_rec = 0;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     auto& g = groups[gi];
-    const size_t cnt_p = padded(g.second.size());
-    const TorMovingSphere& first = objs[g.second[0]].u.moving_sphere;
+    const size_t cnt_p = padded(g.ids.size());
+    const TorMovingSphere& first = objs[g.ids[0]].u.moving_sphere;
     const double t0 = first.time0, dt = first.time1 - first.time0;
     const bool y = yonly[gi] != 0;
     out.segs.insert(out.segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)cnt_p,
                                      (double)(sorted / kPad), t0, dt, 0.0, 0.0});
-    for (size_t k = 0; k < g.second.size(); ++k) {
-      const TorMovingSphere& s = objs[g.second[k]].u.moving_sphere;
+    for (size_t k = 0; k < g.ids.size(); ++k) {
+      const TorMovingSphere& s = objs[g.ids[k]].u.moving_sphere;
       const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
       if (y) {
         double* m = &out.movy[6 * (movy_rec + k)];
@@ -150,10 +213,57 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
         m[3] = s.radius * s.radius;
         m[4] = dcx; m[5] = dcy; m[6] = dcz;
       }
-      if (!fill_cold(&out.cold[16 * (sorted + k)], objs[g.second[k]], g.second[k])) { err = "unknown Material kind"; return false; }
+      if (!fill_cold(&out.cold[16 * (sorted + k)], objs[g.ids[k]], g.ids[k])) { err = "unknown Material kind"; return false; }
     }
     (y ? movy_rec : mov_rec) += cnt_p;
     sorted += cnt_p;
+  }
+
+  // ---- float32 pre-filter segments: pair records {cx cx', cy cy', cz cz', r2 r2', k k' [, dcy dcy' | dcx.. dcy.. dcz..]}
+  size_t f_off = 0;  // float offset into hot32
+  auto emit32 = [&](const std::vector<int64_t>& members, int kind, double t0, double dt) -> bool {
+    const int stride = kind == 5 ? 10 : (kind == 6 ? 12 : 16);
+    const size_t cnt_p = padded(members.size());
+    double mc0max = 0.0, dcmax = 0.0;
+    for (size_t k = 0; k < cnt_p; ++k) {
+      float* rec = &out.hot32[f_off + (k / 2) * (size_t)stride];
+      const int h = (int)(k & 1);
+      if (k >= members.size()) {  // padding: never kept (tor_filter32.hpp)
+        rec[6 + h] = kF32PadR2;
+        continue;
+      }
+      const TorHittableVariant& hv = objs[members[k]];
+      const bool moving = hv.kind == TOR_MOVING_SPHERE;
+      const TorVec3& c0 = moving ? hv.u.moving_sphere.center0 : hv.u.sphere.center;
+      const double r = moving ? hv.u.moving_sphere.radius : hv.u.sphere.radius;
+      const double q[3] = {c0.x - f32->origin[0], c0.y - f32->origin[1], c0.z - f32->origin[2]};
+      const double mc0 = norm3(q[0], q[1], q[2]);
+      rec[0 + h] = (float)q[0]; rec[2 + h] = (float)q[1]; rec[4 + h] = (float)q[2];
+      rec[6 + h] = (float)(r * r);
+      rec[8 + h] = f32_object_k(mc0, r * r, moving);
+      mc0max = std::max(mc0max, mc0);
+      if (moving) {
+        const TorMovingSphere& s = hv.u.moving_sphere;
+        const double dc[3] = {s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z};
+        dcmax = std::max(dcmax, norm3(dc[0], dc[1], dc[2]));
+        if (kind == 6) {
+          rec[10 + h] = (float)dc[1];
+        } else {
+          rec[10 + h] = (float)dc[0]; rec[12 + h] = (float)dc[1]; rec[14 + h] = (float)dc[2];
+        }
+      }
+      if (!fill_cold(&out.cold[16 * (sorted + k)], hv, members[k])) { err = "unknown Material kind"; return false; }
+    }
+    out.segs.insert(out.segs.end(), {(double)kind, (double)f_off, (double)cnt_p, (double)(sorted / kPad), t0, dt,
+                                     (double)f32_round_up(mc0max * 1.000001), (double)f32_round_up(dcmax * 1.000001)});
+    f_off += cnt_p / 2 * (size_t)stride;
+    sorted += cnt_p;
+    return true;
+  };
+  if (!statics32.empty() && !emit32(statics32, 5, 0.0, 1.0)) return false;
+  for (size_t gi = 0; gi < groups32.size(); ++gi) {
+    const TorMovingSphere& first = objs[groups32[gi].ids[0]].u.moving_sphere;
+    if (!emit32(groups32[gi].ids, yonly32[gi] ? 6 : 7, first.time0, first.time1 - first.time0)) return false;
   }
   out.n_segs = (int)(out.segs.size() / 8);
   if (out.segs.empty()) out.segs.assign(8, 0.0);
@@ -175,7 +285,7 @@ bool finite3(const TorVec3& v) { return std::isfinite(v.x) && std::isfinite(v.y)
 
 }  // namespace
 
-void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
+void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, const F32Options* f32) {
   out = HostAccel{};
   if (n < 64) return;  // not worth a second level
   // radius of the typical object
@@ -204,7 +314,7 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out) {
   }
   if (spatial.size() < 32) return;
   std::string err;
-  if (!build_layout(objs, always, out.always, err)) return;
+  if (!build_layout(objs, always, out.always, err, f32)) return;
   // Morton order over the spatial objects' (start) centres
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   auto c0 = [&](int64_t i, int a) {

@@ -14,13 +14,25 @@ namespace tor {
 // Brute-force layout of a subset of the objects (tor_kernels.hpp: stat / movy / mov / segs / cold).
 struct HostLayout {
   std::vector<double> stat, mov, movy, segs, cold;
+  std::vector<float> hot32;  // TOR_ACCEL_F32 segments (kinds 5/6/7): packed pair records, see tor_kernels.hpp
   int n_segs = 0;
   size_t n_sorted = 0;  // cold slots (padded)
 };
 
+// TOR_ACCEL_F32: objects that qualify (tor_filter32.hpp: f32_eligible, and not farther than far_limit from
+// the origin) are laid out for the float32 pre-filter, relative to `origin`; the others keep the float64 loop.
+struct F32Options {
+  double origin[3] = {0.0, 0.0, 0.0};
+  double far_limit = 0.0;
+};
+// Origin = per-axis median of the (start) centres, far_limit = 8 x the median distance from it: robust
+// against a few huge or far-away objects (the ground sphere of random_scene sits 1000 units below).
+F32Options f32_options_for(const TorHittableVariant* objs, int64_t n);
+
 // Builds the layout for objects `ids` (original indices, kept in this order inside each segment).
 // Returns false and sets err for unknown kinds.
-bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& ids, HostLayout& out, std::string& err);
+bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& ids, HostLayout& out, std::string& err,
+                  const F32Options* f32 = nullptr);
 
 // Acceleration layout (TOR_ACCEL_BLOCKS): large or irregular objects stay in an "always" brute-force
 // layout; the rest are sorted along a Morton curve and cut into blocks of 8 consecutive objects.
@@ -40,7 +52,7 @@ struct HostAccel {
   std::vector<Obj> spatial;     // n_blocks * 8 entries (padding: valid = false)
 };
 
-void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out);
+void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, const F32Options* f32 = nullptr);
 
 // 8 float64 per block {lo xyz, hi xyz, 0, 0}: a conservative (inflated) axis-aligned box around the
 // block's spheres over the ray-time range; padded to a multiple of 8 blocks with never-entered (NaN)
