@@ -1,0 +1,32 @@
+"""Where the bounce iteration spends its cycles (debug counters of the wave log): per accel mode on C2."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+tor = importlib.import_module("trace-of-radiance_amd")
+
+H, W, SPP = 1080, 1920, int(os.environ.get("SPP", "20"))
+scene, cam = tor.random_scene(0xFACADE), tor.camera()
+ctx = tor.Context()
+ctx.upload(scene.list())
+buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+for seeding in (tor.SEED_SAMPLE, tor.SEED_PIXEL):
+    for accel in (0, 2, 1, 3):
+        opt = tor.make_options(seeding=seeding, accel=accel)
+        ctx.set_stats(False)
+        ctx.render_device(cam, H, W, SPP, 2.2, 50, opt, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ms = ctx.last_kernel_ms()[0]
+        ctx.set_stats(True)
+        ctx.render_device(cam, H, W, SPP, 2.2, 50, opt, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        wl = ctx.last_wave_log()
+        st = ctx.last_stats()
+        m = (1 << 21) - 1
+        sec = np.stack([wl[:, 6] & m, (wl[:, 6] >> 21) & m, (wl[:, 6] >> 42) & m, wl[:, 7] & m, (wl[:, 7] >> 21) & m,
+                        (wl[:, 7] >> 42) & m], axis=1).astype(np.float64)
+        tot = sec[:, 5].sum()
+        names = ["refill+camera", "object loop", "exact resolve", "shade", "deposit"]
+        share = {n: round(float(sec[:, i].sum() / tot), 3) for i, n in enumerate(names)}
+        print(f"seeding {seeding} accel {accel}: {H * W * SPP / ms / 1e3:8.1f} Msamples/s  kernel {ms:7.2f} ms  "
+              f"cand/query {st.candidates / max(st.hit_queries, 1):.2f}  {share}", flush=True)

@@ -772,14 +772,15 @@ int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double
         unsigned m = 0;
         for (int j = 0; j < tor::kPad / 2; ++j) {
           const float* rec = &lay.hot32[(size_t)begin + (size_t)(i / 2 + j) * stride];
-          f2v cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]};
-          if (kind == 6) cy = tor::fma2((f2v){rec[10], rec[11]}, s32.f, cy);
+          const f2v cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]};
+          f2v ocx = tor::oc_static32(r32.ox, cx), ocy = tor::oc_static32(r32.oy, cy), ocz = tor::oc_static32(r32.oz, cz);
+          if (kind == 6) ocy = tor::oc_moving32(r32.oy, cy, (f2v){rec[10], rec[11]}, s32.nf);
           if (kind == 7) {
-            cx = tor::fma2((f2v){rec[10], rec[11]}, s32.f, cx);
-            cy = tor::fma2((f2v){rec[12], rec[13]}, s32.f, cy);
-            cz = tor::fma2((f2v){rec[14], rec[15]}, s32.f, cz);
+            ocx = tor::oc_moving32(r32.ox, cx, (f2v){rec[10], rec[11]}, s32.nf);
+            ocy = tor::oc_moving32(r32.oy, cy, (f2v){rec[12], rec[13]}, s32.nf);
+            ocz = tor::oc_moving32(r32.oz, cz, (f2v){rec[14], rec[15]}, s32.nf);
           }
-          m = tor::filter_pair32(r32, s32, cx, cy, cz, (f2v){rec[6], rec[7]}, (f2v){rec[8], rec[9]}, m);
+          m = tor::filter_pair32(r32, s32, ocx, ocy, ocz, (f2v){rec[6], rec[7]}, (f2v){rec[8], rec[9]}, m);
         }
         m |= s32.wild;
         for (int j = 0; j < tor::kPad; ++j) {

@@ -10,19 +10,21 @@
 //
 // Error bound (u = 2^-24, all operations round to nearest, no overflow/underflow -- the caller guards the
 // ranges; hats are float32 values, capitals the real-number values of the float64 inputs):
-//   coordinates relative to an origin P near the scene:  o^ = fl(o - P), c^ = fl(c0 - P) [+ fl(dc) * f^]
-//   Lambda := |o-P| + 3.1 Mc + |OC|,  Mc := |c0-P| + |f| |dc|          (Euclidean norms)
-//   |oc^ - OC|           <= 1.001 u Lambda                              (3 roundings of inputs, 1 of the subtraction)
+//   coordinates relative to an origin P near the scene:  o^ = fl(o - P), c0^ = fl(c0 - P), dc^ = fl(dc), f^ = fl(f)
+//   oc^ = fl(o^ - c0^)  [static]   or   fl(fl(o^ - c0^) - f^ dc^)  [moving, one fma]
+//   Lambda := 2|o-P| + 3.1 Mc + |OC|,  Mc := |c0-P| + |f| |dc|         (Euclidean norms)
+//   |oc^ - OC|           <= 1.001 u Lambda                              (input roundings + 2 operation roundings)
 //   |hb^ - HB|           <= 5.02 u |d| Lambda                           (3 products, 3 roundings)
 //   |c^  - C |           <= u (2.01 |OC| Lambda + 3.02 |OC|^2 + 4.02 r^2) + u^2 Lambda^2
 // The filter evaluates, per object,
-//   hb'' = hb^ - mbl          mbl >= 5.1 u |d| (2|o-P| + 4.1 max Mc)   =>  HB < 0  implies  hb'' < 0 and |hb''| >= |HB|
-//   y    = m - a^ c^          m   >= 1.002 u A (9.81 c^ + 15.84 r^2 + 7.25 Mc^2 + 0.754 |o-P|^2)
+//   hb'' = hb^ - mbl          mbl >= 5.1 u |d| (3|o-P| + 4.1 max Mc)   =>  HB < 0  implies  hb'' < 0 and |hb''| >= |HB|
+//   y    = m - a^ c^          m   >= 1.002 u A (9.81 c^ + 15.84 r^2 + 7.25 Mc^2 + 3.02 |o-P|^2)
+//                             evaluated as  c^ (g - a^) + (g k + gK),  g = 10.5 u a^  (two fmas)
 //   D''  = hb''^2 + y
 // and keeps the object iff  D'' >= 0  and  (hb'' < 0  or  y >= 0)   [sign bits only].
 //   * C < 0           =>  c^ < E_c <= m / a^  =>  y >= 0, and then D'' >= 0 as a sum of non-negatives;
 //   * HB < 0, D > 0   =>  hb''^2 + y >= HB^2 - A C + (m - error terms) >= D > 0.
-// (2.01 |OC| Lambda <= 4.02 |OC|^2 + 0.2513 Lambda^2 and Lambda^2 <= 3 (|o-P|^2 + 9.61 Mc^2 + |OC|^2) turn the
+// (2.01 |OC| Lambda <= 4.02 |OC|^2 + 0.2513 Lambda^2 and Lambda^2 <= 3 (4 |o-P|^2 + 9.61 Mc^2 + |OC|^2) turn the
 // bound into the linear form above; |OC|^2 = C + r^2.)  The constants below carry a further 5-8 % of slack,
 // which also covers the roundings of the margin arithmetic itself and the 2^-50-relative gap between the
 // float64-computed D, HB, C and their real values.  For |o-P|, |c-P| ~ 15 and r = 0.2 (random_scene) the
@@ -45,7 +47,7 @@ TOR_HD f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c)
 constexpr float kU32 = 0x1p-24f;
 constexpr float kF32Gain = 10.5f * kU32;  // >= 1.002 * 9.81 u, + slack
 constexpr float kF32Mbl = 5.5f * kU32;    // >= 5.1 u, + slack
-constexpr float kF32KRo = 0.08f;          // >= 0.754 / 9.81
+constexpr float kF32KRo = 0.32f;          // >= 3.02 / 9.81
 constexpr float kF32KDc = 1.5f;           // >= 2 * 7.25 / 9.81   (Mc^2 <= 2 |c0-P|^2 + 2 f^2 |dc|^2)
 constexpr double kF32KR2 = 1.65;          // >= 15.84 / 9.81      (host: per-object constant k)
 constexpr double kF32KMc = 0.75;          // >= 7.25 / 9.81
@@ -55,7 +57,7 @@ constexpr float kF32PadR2 = -1e30f;       // r^2 of a padding record: c^ ~ 1e30,
 // per query
 struct RayF32 {
   float ox, oy, oz, dx, dy, dz;  // o - P and d, rounded to float32
-  float na, g;                   // -a and the margin gain * a
+  float gma, g;                  // g - a and g = margin gain * a
   float ro, ro2, sa;             // |o-P|, |o-P|^2, sqrt(a)
   unsigned wild;                 // 0xff: ranges not guaranteed -> the lane keeps every object
 };
@@ -66,8 +68,8 @@ TOR_HD RayF32 make_ray_f32(double ox, double oy, double oz, double dx, double dy
   r.ox = (float)(ox - px); r.oy = (float)(oy - py); r.oz = (float)(oz - pz);
   r.dx = (float)dx; r.dy = (float)dy; r.dz = (float)dz;
   const float fa = (float)a;
-  r.na = -fa;
   r.g = kF32Gain * fa;
+  r.gma = r.g - fa;
   r.ro2 = __builtin_fmaf(r.oz, r.oz, __builtin_fmaf(r.oy, r.oy, r.ox * r.ox));
   r.ro = __builtin_sqrtf(r.ro2);
   r.sa = __builtin_sqrtf(fa);
@@ -79,7 +81,7 @@ TOR_HD RayF32 make_ray_f32(double ox, double oy, double oz, double dx, double dy
 // per query and segment (a segment = objects sharing (time0, time1); f = (time - time0)/(time1 - time0),
 // 0 for static spheres; mc0max / dcmax = max |c0-P| / max |dc| over the segment, rounded up)
 struct SegF32 {
-  f2v nmbl, gk, f;
+  f2v nmbl, gk, nf;  // -mbl, g * K (the per-lane part of the margin), -f
   unsigned wild;
 };
 
@@ -89,21 +91,24 @@ TOR_HD SegF32 make_seg_f32(const RayF32& r, double f64, float mc0max, float dcma
   const float af = __builtin_fabsf(f);
   s.wild = (af <= kF32Lim) ? r.wild : 0xffu;  // NaN -> wild
   const float mcl = mc0max + af * dcmax;
-  s.nmbl = splat2(-(kF32Mbl * r.sa * (2.0f * r.ro + 4.2f * mcl)));
+  s.nmbl = splat2(-(kF32Mbl * r.sa * (3.0f * r.ro + 4.2f * mcl)));
   s.gk = splat2(r.g * (kF32KRo * r.ro2 + kF32KDc * ((f * f) * (dcmax * dcmax))));
-  s.f = splat2(f);
+  s.nf = splat2(-f);
   return s;
 }
 
-// Two objects (the halves of the vectors) against one ray; pushes their keep-bits into m (first object
-// ends up in the higher bit, as the float64 loops do).  k = 1.65 r^2 + 0.75 (1|2) |c0-P|^2 per object.
-TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v cx, f2v cy, f2v cz, f2v r2, f2v k,
+// o - c for one axis of two objects: static, or moving along that axis (centre c0 + f dc)
+TOR_HD f2v oc_static32(float o, f2v c0) { return splat2(o) - c0; }
+TOR_HD f2v oc_moving32(float o, f2v c0, f2v dc, f2v nf) { return fma2(nf, dc, splat2(o) - c0); }
+
+// Two objects (the halves of the vectors) against one ray, given o - c per axis; pushes their keep-bits into
+// m (first object ends up in the higher bit, as the float64 loops do).
+// k = 1.65 r^2 + 0.75 (1|2) |c0-P|^2 per object.  12 packed + 4 integer instructions.
+TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v ocx, f2v ocy, f2v ocz, f2v r2, f2v k,
                               unsigned m) {
-  const f2v ocx = splat2(r.ox) - cx, ocy = splat2(r.oy) - cy, ocz = splat2(r.oz) - cz;
   const f2v hb = fma2(ocz, splat2(r.dz), fma2(ocy, splat2(r.dy), fma2(ocx, splat2(r.dx), s.nmbl)));
   const f2v cc = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, -r2)));
-  const f2v mm = fma2(splat2(r.g), cc + k, s.gk);
-  const f2v y = fma2(splat2(r.na), cc, mm);
+  const f2v y = fma2(cc, splat2(r.gma), fma2(splat2(r.g), k, s.gk));
   const f2v dd = fma2(hb, hb, y);
   // keep = (sign(hb) | ~sign(y)) & ~sign(D''): one v_bitop3_b32 (truth table 0x51), bit 31.
   // (Elements are copied to scalars first: __builtin_bit_cast applied directly to `v.y` reads element 0.)
@@ -146,13 +151,16 @@ inline unsigned filter_one(const double o[3], const double d[3], const double c0
   const double dcn = moving ? std::sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]) : 0.0;
   if (!f32_eligible(mc0, dcn, r2)) return 1u;  // such an object stays on the float64 path
   const SegF32 s = make_seg_f32(r, moving ? f64 : 0.0, f32_round_up(mc0), f32_round_up(dcn));
-  f2v cx = splat2((float)q[0]), cy = splat2((float)q[1]), cz = splat2((float)q[2]);
+  const f2v cx = splat2((float)q[0]), cy = splat2((float)q[1]), cz = splat2((float)q[2]);
+  f2v ocx, ocy, ocz;
   if (moving) {
-    cx = fma2(splat2((float)dc[0]), s.f, cx);
-    cy = fma2(splat2((float)dc[1]), s.f, cy);
-    cz = fma2(splat2((float)dc[2]), s.f, cz);
+    ocx = oc_moving32(r.ox, cx, splat2((float)dc[0]), s.nf);
+    ocy = oc_moving32(r.oy, cy, splat2((float)dc[1]), s.nf);
+    ocz = oc_moving32(r.oz, cz, splat2((float)dc[2]), s.nf);
+  } else {
+    ocx = oc_static32(r.ox, cx); ocy = oc_static32(r.oy, cy); ocz = oc_static32(r.oz, cz);
   }
-  unsigned m = filter_pair32(r, s, cx, cy, cz, splat2((float)r2), splat2(f32_object_k(mc0, r2, moving)), 0u);
+  unsigned m = filter_pair32(r, s, ocx, ocy, ocz, splat2((float)r2), splat2(f32_object_k(mc0, r2, moving)), 0u);
   return ((m | s.wild) & 1u);
 }
 

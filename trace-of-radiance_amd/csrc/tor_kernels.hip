@@ -191,6 +191,17 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
   const unsigned long long t_start = (p.wave_log != nullptr) ? wall_clock64() : 0ull;
   unsigned long long t_exh = 0, it_exh = 0;
+  // debug (wave_log only): shader-clock cycles per section of the bounce iteration
+  const bool prof = p.wave_log != nullptr;
+  unsigned long long sec_refill = 0, sec_loop = 0, sec_resolve = 0, sec_shade = 0, sec_deposit = 0, sec_mark = 0;
+  const unsigned long long sec_begin = prof ? __builtin_readcyclecounter() : 0ull;
+#define TOR_SEC(acc)                                        \
+  if (prof) {                                               \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc += now_ - sec_mark;                                 \
+    sec_mark = now_;                                        \
+  }
+  sec_mark = sec_begin;
 
   for (;;) {
     // ================= (A) refill lanes that have no live path =========================
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       depth = 0;
       active = true;
     }
+    TOR_SEC(sec_refill)
     const unsigned long long active_mask = ballot64(active);
     if (active_mask == 0) {
       if (exhausted) break;
@@ -356,8 +368,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 #pragma unroll
                 for (int j = 0; j < kBlock / 2; ++j) {
                   cfptr r = rec + 10 * j;
-                  m = filter_pair32(r32, s32, (f2v){r[0], r[1]}, (f2v){r[2], r[3]}, (f2v){r[4], r[5]},
-                                    (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
+                  m = filter_pair32(r32, s32, oc_static32(r32.ox, (f2v){r[0], r[1]}), oc_static32(r32.oy, (f2v){r[2], r[3]}),
+                                    oc_static32(r32.oz, (f2v){r[4], r[5]}), (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
                 }
                 rec += 10 * (kBlock / 2);
                 m |= s32.wild;
@@ -371,9 +383,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 #pragma unroll
                 for (int j = 0; j < kBlock / 2; ++j) {
                   cfptr r = rec + 12 * j;
-                  const f2v cy = fma2((f2v){r[10], r[11]}, s32.f, (f2v){r[2], r[3]});
-                  m = filter_pair32(r32, s32, (f2v){r[0], r[1]}, cy, (f2v){r[4], r[5]}, (f2v){r[6], r[7]},
-                                    (f2v){r[8], r[9]}, m);
+                  m = filter_pair32(r32, s32, oc_static32(r32.ox, (f2v){r[0], r[1]}),
+                                    oc_moving32(r32.oy, (f2v){r[2], r[3]}, (f2v){r[10], r[11]}, s32.nf),
+                                    oc_static32(r32.oz, (f2v){r[4], r[5]}), (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
                 }
                 rec += 12 * (kBlock / 2);
                 m |= s32.wild;
@@ -387,10 +399,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 #pragma unroll
                 for (int j = 0; j < kBlock / 2; ++j) {
                   cfptr r = rec + 16 * j;
-                  const f2v cx = fma2((f2v){r[10], r[11]}, s32.f, (f2v){r[0], r[1]});
-                  const f2v cy = fma2((f2v){r[12], r[13]}, s32.f, (f2v){r[2], r[3]});
-                  const f2v cz = fma2((f2v){r[14], r[15]}, s32.f, (f2v){r[4], r[5]});
-                  m = filter_pair32(r32, s32, cx, cy, cz, (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
+                  m = filter_pair32(r32, s32, oc_moving32(r32.ox, (f2v){r[0], r[1]}, (f2v){r[10], r[11]}, s32.nf),
+                                    oc_moving32(r32.oy, (f2v){r[2], r[3]}, (f2v){r[12], r[13]}, s32.nf),
+                                    oc_moving32(r32.oz, (f2v){r[4], r[5]}, (f2v){r[14], r[15]}, s32.nf),
+                                    (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m);
                 }
                 rec += 16 * (kBlock / 2);
                 m |= s32.wild;
@@ -476,6 +488,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           i = 0;
         }
 
+        TOR_SEC(sec_loop)
         // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
         // Queue entries are 8-bit masks over 8 consecutive cold slots (direct candidates) or, flagged
         // with bit 31, over 8 block bounds.  A trip of the loop handles one set bit per lane: either
@@ -623,6 +636,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             }
           }
         }
+        TOR_SEC(sec_resolve)
         if (!full) break;
       }
 
@@ -705,6 +719,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       }
     }
 
+    TOR_SEC(sec_shade)
     if (SEEDING == 1) {
       // ---- deposit finished samples: exact (2^-36-quantised) float64 sums, any order ------
       // The wave keeps the pixels it is currently filling in a small LDS cache (pixels arrive
@@ -735,7 +750,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         ended_mask &= ~ballot64(mine);
       }
     }
+    TOR_SEC(sec_deposit)
   }
+#undef TOR_SEC
 
   if (SEEDING == 1) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -755,7 +772,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       unsigned long long* w = p.wave_log + (size_t)(blockIdx.x * (kThreads / 64) + wave) * 8;
       w[0] = t_start; w[1] = wall_clock64(); w[2] = st_iters;
       w[3] = st_queries | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
-      w[4] = t_exh; w[5] = it_exh; w[6] = 0; w[7] = 0;
+      w[4] = t_exh; w[5] = it_exh;
+      // six 21-bit fields in units of 4096 shader cycles: refill+camera, object loop, exact resolve | shade, deposit, total
+      const unsigned long long total = __builtin_readcyclecounter() - sec_begin;
+      auto f21 = [](unsigned long long c) { c >>= 12; return c > 0x1fffffull ? 0x1fffffull : c; };
+      w[6] = f21(sec_refill) | (f21(sec_loop) << 21) | (f21(sec_resolve) << 42);
+      w[7] = f21(sec_shade) | (f21(sec_deposit) << 21) | (f21(total) << 42);
     }
     if (lane == 0) {
       atomicAdd(p.stats + 0, st_queries);
