@@ -108,8 +108,8 @@ struct DeviceLayout {
 // device copy of a tor::HostAccel (TOR_ACCEL_BLOCKS): always-list + spatial blocks
 struct DeviceAccel {
   DeviceLayout always;  // .cold holds always.cold followed by the spatial objects' cold records
-  DeviceBuffer hot, grp;
-  void release() { always.release(); hot.release(); grp.release(); }
+  DeviceBuffer hot, grp, hot32;
+  void release() { always.release(); hot.release(); grp.release(); hot32.release(); }
 };
 
 }  // namespace
@@ -290,6 +290,10 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
       HIP_TRY(ctx->d_accel[v].always.put(ctx->accel[v].always, &ctx->accel[v].cold));
       HIP_TRY(put(ctx->d_accel[v].hot, ctx->accel[v].hot));
       HIP_TRY(put(ctx->d_accel[v].grp, ctx->accel[v].groups));
+      if (ctx->accel[v].sp32) {
+        HIP_TRY(ctx->d_accel[v].hot32.ensure(ctx->accel[v].hot32.size() * 4));
+        HIP_TRY(hipMemcpy(ctx->d_accel[v].hot32.ptr, ctx->accel[v].hot32.data(), ctx->accel[v].hot32.size() * 4, hipMemcpyHostToDevice));
+      }
       const size_t n_bnd_p = (ctx->accel[v].n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
       const size_t n_super_p = (n_bnd_p / tor::kPad + tor::kPad - 1) / tor::kPad * tor::kPad;
       ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * 8;
@@ -347,7 +351,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
   tor::KParams p{};
-  const int v32 = (o.accel & TOR_ACCEL_F32) ? 1 : 0;
+  // TOR_ACCEL_F32 layout variant; with TOR_ACCEL_BLOCKS it needs float32 block records (HostAccel::sp32),
+  // otherwise the whole launch stays on the float64 layout
+  int v32 = (o.accel & TOR_ACCEL_F32) ? 1 : 0;
+  if (v32 && (o.accel & TOR_ACCEL_BLOCKS) && ctx->accel[1].available && !ctx->accel[1].sp32) v32 = 0;
   auto use_layout = [&](const DeviceLayout& L) {
     p.stat = (const double*)L.stat.ptr;
     p.mov = (const double*)L.mov.ptr;
@@ -386,14 +393,26 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.shot_stride = hacc.hot_stride;
     // LDS staging of the compact records next to the per-wave queues (18 KB per workgroup, 160 KB per
     // CU): it must fit at this mode's workgroups/CU, else one workgroup fewer, else global loads.
-    const size_t hot_bytes = hacc.hot.size() * 8;
+    p.shot32 = nullptr;
+    if (v32 && hacc.sp32) {
+      p.shot32 = (const float*)ctx->d_accel[v32].hot32.ptr;
+      p.shot32_stride = hacc.hot32_stride;
+      p.sp_mc0max = hacc.sp_mc0max; p.sp_dcmax = hacc.sp_dcmax;
+      p.sp_t0 = hacc.sp_t0; p.sp_dt = hacc.sp_dt;
+    }
+    // LDS staging of the block records next to the per-wave queues (18 KB per workgroup, 160 KB per CU): the
+    // float32 pair records (TOR_ACCEL_F32; survivors are re-tested from the cold records -- staging the float64
+    // records as well measured +2 % at best) or the float64 compact records.  It must fit at this mode's
+    // workgroups/CU, else one workgroup fewer, else global loads.
+    const size_t hot_bytes = p.shot32 ? hacc.hot32.size() * 4 : hacc.hot.size() * 8;
     const char* st = std::getenv("TOR_STAGE_LDS");
     const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
     int& wg = stage_wg;
     wg = 0;
     for (int tryw = ctx->max_blocks_per_cu[o.seeding]; tryw >= 2 && wg == 0; --tryw)
       if (hot_bytes <= hard_cap && hot_bytes + 18432 <= (size_t)(160 * 1024) / (size_t)tryw - 1024) wg = tryw;
-    p.shot_lds_doubles = wg > 0 ? (int)hacc.hot.size() : 0;
+    p.shot_lds_doubles = (wg > 0 && !p.shot32) ? (int)hacc.hot.size() : 0;
+    p.shot32_lds_floats = (wg > 0 && p.shot32) ? (int)hacc.hot32.size() : 0;
   }
   // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
   // kernel variant's register budget follows it
@@ -401,7 +420,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (cap < 1) cap = 4;
   if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
   const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
-  int bpc_eff = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd, p.hot32 != nullptr ? 1 : 0);
+  int bpc_eff = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd, (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0);
   if (bpc_eff > cap) bpc_eff = cap;
   const long long resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;

@@ -55,6 +55,8 @@ namespace tor {
 typedef const double __attribute__((address_space(4))) * cdptr;
 typedef const float __attribute__((address_space(4))) * cfptr;
 typedef const double __attribute__((address_space(3))) * ldptr;  // LDS
+typedef const float __attribute__((address_space(3))) * lfptr;
+typedef const float __attribute__((address_space(1))) * gfptr;
 typedef const double __attribute__((address_space(1))) * gdptr;  // global
 
 __device__ __forceinline__ cdptr as_const(const double* p) { return (cdptr)(uintptr_t)p; }
@@ -155,11 +157,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
   // TOR_ACCEL_BLOCKS: the block expansion gathers 8 x 64 B per lane and trip with 64 different
   // addresses; when the compact records fit they are staged in LDS once per workgroup.
-  const bool staged = p.shot_lds_doubles > 0;
+  const bool staged = p.shot_lds_doubles > 0 || p.shot32_lds_floats > 0;
   double* stage = reinterpret_cast<double*>(smem_raw + (kThreads / 64) * kWaveLdsBytes);
   const ldptr shot_lds = (ldptr)stage;
+  // (a launch stages either the float64 compact records or the float32 pair records)
+  float* stage32 = reinterpret_cast<float*>(stage);
+  const lfptr shot32_lds = (lfptr)stage32;
   if (staged) {
-    for (int k = threadIdx.x; k < p.shot_lds_doubles; k += kThreads) stage[k] = p.shot[k];
+    if (F32) {
+      for (int k = threadIdx.x; k < p.shot32_lds_floats; k += kThreads) stage32[k] = p.shot32[k];
+    } else {
+      for (int k = threadIdx.x; k < p.shot_lds_doubles; k += kThreads) stage[k] = p.shot[k];
+    }
     __syncthreads();
   }
 
@@ -548,6 +557,24 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             }
           }
         };
+        // exact hit of the object in cold slot `slot` (centre from the cold record)
+        auto exact_cold = [&](unsigned slot) {
+          const double* c = p.cold + (size_t)slot * 16;
+          double cx = c[0], cy = c[1], cz = c[2], f = 0.0;
+          const int flags = (int)__double_as_longlong(c[13]);
+          if (flags & 1) {
+            f = (time - c[7]) / c[8];
+            if (ARITH == 0) {
+              cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f;
+            } else {
+              cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz);
+            }
+          }
+          exact_hit(cx, cy, cz, c[15], slot, f);
+        };
+        // TOR_ACCEL_F32 block expansion: the spatial movers share one time group
+        SegF32 sp32{};
+        if (F32 && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
         unsigned kq = 0, cur_mask = 0, cur_block = 0, cur_is_bound = 0;
         for (;;) {
           if (cur_mask == 0 && kq < qn) {
@@ -583,11 +610,54 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   exact_hit(cx, cy, cz, blk[hs * j + 3], (unsigned)p.spatial_base + blk_id * kBlock + (unsigned)j, f);
                 }
               };
+              // the same through the float32 pre-filter: 4 pair records of ST floats (tor_filter32.hpp)
+              auto expand32 = [&](auto blk, auto ST, unsigned blk_id) {
+                constexpr int st = decltype(ST)::value;
+                unsigned m8 = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock / 2; ++j) {
+                  auto r = blk + st * j;
+                  const f2v c0x = {r[0], r[1]}, c0y = {r[2], r[3]}, c0z = {r[4], r[5]};
+                  f2v ocx, ocy, ocz;
+                  if (st == 16) {
+                    ocx = oc_moving32(r32.ox, c0x, (f2v){r[10], r[11]}, sp32.nf);
+                    ocy = oc_moving32(r32.oy, c0y, (f2v){r[12], r[13]}, sp32.nf);
+                    ocz = oc_moving32(r32.oz, c0z, (f2v){r[14], r[15]}, sp32.nf);
+                  } else {
+                    ocx = oc_static32(r32.ox, c0x);
+                    ocy = (st == 12) ? oc_moving32(r32.oy, c0y, (f2v){r[10], r[11]}, sp32.nf) : oc_static32(r32.oy, c0y);
+                    ocz = oc_static32(r32.oz, c0z);
+                  }
+                  m8 = filter_pair32(r32, sp32, ocx, ocy, ocz, (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m8);
+                }
+                m8 |= sp32.wild;
+                while (m8 != 0) {
+                  const int bb = 31 - __builtin_clz(m8);
+                  m8 &= ~(1u << bb);
+                  exact_cold((unsigned)p.spatial_base + blk_id * kBlock + (unsigned)(7 - bb));
+                }
+              };
               using S8 = std::integral_constant<int, 8>;
               using S4 = std::integral_constant<int, 4>;
+              using T10 = std::integral_constant<int, 10>;
+              using T12 = std::integral_constant<int, 12>;
+              using T16 = std::integral_constant<int, 16>;
               auto expand_block = [&](unsigned blk_id) {
                 st_cand += kBlock;
-                if (p.shot_stride == 8) {
+                if constexpr (F32 != 0) {
+                  // (the host pairs the float32 kernel variant with float32 block records, or with no blocks at all)
+                  const size_t off = (size_t)blk_id * (size_t)(p.shot32_stride * (kBlock / 2));
+                  if (p.shot32_lds_floats > 0) {
+                    if (p.shot32_stride == 12) expand32(shot32_lds + off, T12{}, blk_id);
+                    else if (p.shot32_stride == 10) expand32(shot32_lds + off, T10{}, blk_id);
+                    else expand32(shot32_lds + off, T16{}, blk_id);
+                  } else {
+                    const gfptr g32 = (gfptr)(uintptr_t)p.shot32;
+                    if (p.shot32_stride == 12) expand32(g32 + off, T12{}, blk_id);
+                    else if (p.shot32_stride == 10) expand32(g32 + off, T10{}, blk_id);
+                    else expand32(g32 + off, T16{}, blk_id);
+                  }
+                } else if (p.shot_stride == 8) {  // float64 compact records
                   if (staged) expand(shot_lds + (size_t)blk_id * (8 * kBlock), S8{}, blk_id);            // ds_read
                   else expand((gdptr)(uintptr_t)p.shot + (size_t)blk_id * (8 * kBlock), S8{}, blk_id);  // global_load
                 } else {
@@ -621,18 +691,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               }
             } else {
               st_cand += 1;
-              const double* c = p.cold + (size_t)rec * 16;
-              double cx = c[0], cy = c[1], cz = c[2], f = 0.0;
-              const int flags = (int)__double_as_longlong(c[13]);
-              if (flags & 1) {
-                f = (time - c[7]) / c[8];
-                if (ARITH == 0) {
-                  cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f;
-                } else {
-                  cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz);
-                }
-              }
-              exact_hit(cx, cy, cz, c[15], rec, f);
+              exact_cold(rec);
             }
           }
         }
@@ -927,8 +986,8 @@ static int clamp_w(int waves_per_simd, int f32) {
 }
 
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
-  if (p.hot32 != nullptr)
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4;
+  if (p.hot32 != nullptr || p.shot32 != nullptr)
     hipLaunchKernelGGL((integrate_kernel<2, 0, 3, 1>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
   else
     hipLaunchKernelGGL((integrate_kernel<2, 0, 3, 0>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
@@ -942,10 +1001,10 @@ hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles,
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream) {
-  const int f32 = p.hot32 != nullptr ? 1 : 0;
+  const int f32 = (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0;
   IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd, f32), f32);
   if (!fn) return hipErrorInvalidValue;
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8;
+  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
   return hipGetLastError();
 }

@@ -42,6 +42,13 @@ struct KParams {
   int shot_stride;       // float64 per compact record: 8, or 4 when no spatial object moves
   int shot_lds_doubles;  // > 0: copy that many float64 of shot into LDS per workgroup (fits next to the queues)
   const double* sgrp;  // TOR_ACCEL_BLOCKS: {time0, time1 - time0} per time group
+  // TOR_ACCEL_BLOCKS | TOR_ACCEL_F32: float32 pair records of the spatial slots (4 pairs of shot32_stride floats
+  // per block), replacing shot/sgrp in the block expansion; null -> float64 expansion
+  const float* shot32;
+  int shot32_stride;      // 10 | 12 | 16 floats per pair
+  int shot32_lds_floats;  // > 0: copy that many floats of shot32 into LDS per workgroup
+  float sp_mc0max, sp_dcmax;
+  double sp_t0, sp_dt;    // the spatial movers' time group
   int spatial_base;    // first cold slot of the spatial blocks: block b owns cold[spatial_base + 8b .. +8)
   int n_segs;
   int nrows, ncols, spp, max_depth;

@@ -397,6 +397,50 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
     out.hot.swap(packed);
     out.hot_stride = 4;
   }
+  // float32 records for the per-lane block expansion
+  if (f32 && out.groups.size() <= 2) {
+    bool ok = true, any_mover = false, y_only = true;
+    double mc0max = 0.0, dcmax = 0.0;
+    for (const HostAccel::Obj& o : out.spatial) {
+      if (!o.valid) continue;
+      const double mc0 = norm3(o.c0[0] - f32->origin[0], o.c0[1] - f32->origin[1], o.c0[2] - f32->origin[2]);
+      const double dcn = o.moving ? norm3(o.dc[0], o.dc[1], o.dc[2]) : 0.0;
+      ok = ok && f32_eligible(mc0, dcn, o.abs_r * o.abs_r) && mc0 <= f32->far_limit;
+      mc0max = std::max(mc0max, mc0);
+      dcmax = std::max(dcmax, dcn);
+      if (o.moving) {
+        any_mover = true;
+        y_only = y_only && o.dc[0] == 0.0 && o.dc[2] == 0.0;
+      }
+    }
+    if (ok) {
+      out.sp32 = true;
+      out.hot32_stride = !any_mover ? 10 : (y_only ? 12 : 16);
+      const int st = out.hot32_stride;
+      const size_t slots = n_bnd_slots * kPad;
+      out.hot32.assign(slots / 2 * (size_t)st + 32, 0.0f);
+      for (size_t k = 0; k < slots; ++k) {
+        float* rec = &out.hot32[(k / 2) * (size_t)st];
+        const int h = (int)(k & 1);
+        const HostAccel::Obj* o = k < out.spatial.size() && out.spatial[k].valid ? &out.spatial[k] : nullptr;
+        if (!o) {
+          rec[6 + h] = kF32PadR2;
+          continue;
+        }
+        const double q[3] = {o->c0[0] - f32->origin[0], o->c0[1] - f32->origin[1], o->c0[2] - f32->origin[2]};
+        rec[0 + h] = (float)q[0]; rec[2 + h] = (float)q[1]; rec[4 + h] = (float)q[2];
+        rec[6 + h] = (float)(o->abs_r * o->abs_r);
+        rec[8 + h] = f32_object_k(norm3(q[0], q[1], q[2]), o->abs_r * o->abs_r, o->moving);
+        if (o->moving) {
+          if (st == 12) rec[10 + h] = (float)o->dc[1];
+          else { rec[10 + h] = (float)o->dc[0]; rec[12 + h] = (float)o->dc[1]; rec[14 + h] = (float)o->dc[2]; }
+          out.sp_t0 = o->t0; out.sp_dt = o->dt;
+        }
+      }
+      out.sp_mc0max = f32_round_up(mc0max * 1.000001);
+      out.sp_dcmax = f32_round_up(dcmax * 1.000001);
+    }
+  }
   out.available = true;
 }
 

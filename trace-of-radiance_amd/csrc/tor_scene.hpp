@@ -50,6 +50,15 @@ struct HostAccel {
   bool two_level = false;       // the uniform loop tests boxes around 8 blocks; lanes descend to the block boxes
   struct Obj { double c0[3], dc[3], t0, dt, abs_r; bool moving, valid; };
   std::vector<Obj> spatial;     // n_blocks * 8 entries (padding: valid = false)
+  // TOR_ACCEL_F32 block expansion: float32 pair records of the spatial slots (tor_filter32.hpp), 4 pairs per
+  // block, hot32_stride floats per pair: 10 {cx cx' cy cy' cz cz' r2 r2' k k'} (no mover), 12 (+ dcy dcy':
+  // movers along y only), 16 (+ dcx.. dcy.. dcz..).  Built when every spatial object qualifies for the
+  // filter and the movers share one (time0, time1); otherwise the lanes expand the float64 records.
+  bool sp32 = false;
+  std::vector<float> hot32;
+  int hot32_stride = 10;
+  double sp_t0 = 0.0, sp_dt = 1.0;      // the movers' time group
+  float sp_mc0max = 0.0f, sp_dcmax = 0.0f;  // max |c0 - origin| and |dc| over the spatial objects (rounded up)
 };
 
 void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, const F32Options* f32 = nullptr);
