@@ -241,9 +241,11 @@ typedef struct TorStats {
 } TorStats;
 TOR_API int tor_context_set_stats(TorContext* ctx, int32_t enable);
 TOR_API int tor_last_stats(TorContext* ctx, TorStats* out);
-/* Debug: 8 x u64 per wave {start, end (100 MHz wall clock), bounce iterations, closest-hit queries |
- * HW_ID << 44, time and iteration count when the work counter ran dry, 0, 0} of the last launch
- * (stats enabled).  Returns the number of waves copied (<= cap_waves) or < 0. */
+/* Debug: 8 x u64 per wave of the last launch (stats enabled): {start, end (100 MHz wall clock), bounce
+ * iterations, closest-hit queries | HW_ID << 44, time when the work counter ran dry, iteration count at that
+ * time | trips of the resolve loop << 32, and two words of six 21-bit fields in units of 4096 shader cycles:
+ * refill + camera ray, object loop, exact resolve | shade, deposit, total}.
+ * Returns the number of waves copied (<= cap_waves) or < 0. */
 TOR_API int tor_last_wave_log(TorContext* ctx, uint64_t* out, int64_t cap_waves);
 
 /* ------------------------------------------------------------------------------------ */

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
   const unsigned long long t_start = (p.wave_log != nullptr) ? wall_clock64() : 0ull;
   unsigned long long t_exh = 0, it_exh = 0;
+  unsigned st_trips = 0;  // debug: trips of the deferred resolve loop (wave level)
   // debug (wave_log only): shader-clock cycles per section of the bounce iteration
   const bool prof = p.wave_log != nullptr;
   unsigned long long sec_refill = 0, sec_loop = 0, sec_resolve = 0, sec_shade = 0, sec_deposit = 0, sec_mark = 0;
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
           const bool has = cur_mask != 0;
           if (ballot64(has) == 0) break;
+          st_trips += 1;
           if (has) {
             const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> record j of the group
             cur_mask &= ~(1u << b);
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       unsigned long long* w = p.wave_log + (size_t)(blockIdx.x * (kThreads / 64) + wave) * 8;
       w[0] = t_start; w[1] = wall_clock64(); w[2] = st_iters;
       w[3] = st_queries | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
-      w[4] = t_exh; w[5] = it_exh;
+      w[4] = t_exh; w[5] = (it_exh & 0xffffffffull) | ((unsigned long long)st_trips << 32);
       // six 21-bit fields in units of 4096 shader cycles: refill+camera, object loop, exact resolve | shade, deposit, total
       const unsigned long long total = __builtin_readcyclecounter() - sec_begin;
       auto f21 = [](unsigned long long c) { c >>= 12; return c > 0x1fffffull ? 0x1fffffull : c; };
