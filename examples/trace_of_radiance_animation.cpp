@@ -1,8 +1,8 @@
 // trace_of_radiance_animation.cpp -- the reference's video driver (trace_of_radiance_animation.nim:
 // main_animation_mp4, :101-214, "fast test" constants :107-119) on top of the C ABI of
 // libtor_mi355x.so: bouncing-spheres animation, one render per frame, RGB -> Y'CbCr 4:2:0 -> I_PCM
-// H.264 on the device, an Annex-B `animation.264` on disk (the reference then muxes that file into
-// MP4 with the vendored minimp4; `ffmpeg -i animation.264 -c copy animation.mp4` does the same).
+// H.264 on the device, an Annex-B `animation.264` on disk, then muxed into `animation.mp4`
+// (MP4Muxer, :203-210; 30 frames per second as io/mp4.nim:141).
 //
 //   g++ -O2 -I include examples/trace_of_radiance_animation.cpp -L trace-of-radiance_amd/lib \
 //       -ltor_mi355x -Wl,-rpath,'$ORIGIN/../trace-of-radiance_amd/lib' -o examples/trace_of_radiance_animation
@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "tor_render.h"
@@ -71,5 +72,15 @@ int main(int argc, char** argv) {
   tor_animation_destroy(anim);
   std::fprintf(stderr, "%d frames (%dx%d, %d spp) in %.3f s -> %s\n", scene_id, image_width, image_height, samples_per_pixel,
                elapsed, path);
+  // Muxing into MP4 (:203-210): <name>.264 -> <name>.mp4
+  std::string mp4 = path;
+  const size_t dot = mp4.rfind('.');
+  mp4 = (dot == std::string::npos ? mp4 : mp4.substr(0, dot)) + ".mp4";
+  const int samples = tor_mp4_mux_file(path, mp4.c_str(), image_width, image_height, 30);
+  if (samples != scene_id) {
+    std::fprintf(stderr, "muxing failed: %s\n", tor_last_error());
+    return 1;
+  }
+  std::fprintf(stderr, "Finished! Rendering available at \"%s\"\n", mp4.c_str());
   return 0;
 }

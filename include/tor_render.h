@@ -206,10 +206,16 @@ TOR_API int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, in
  *   tor_encode_frame_device: d_pixels = finished canvas (nrows*ncols*3 float64, row 0 = bottom);
  *                            d_slice receives tor_h264_frame_bytes() bytes; d_y/d_cb/d_cr (nullable)
  *                            receive the planes (H264Encoder.getFrameBuffers, h264.nim:206-224).
- * Concatenating header + slices gives the Annex-B .264 file of main_animation_mp4; MP4 muxing
- * (io/mp4.nim -> vendored minimp4) stays on the host and is out of scope. */
+ * Concatenating header + slices gives the Annex-B .264 file of main_animation_mp4;
+ * tor_mp4_mux_file wraps it into the .mp4 (host side). */
 TOR_API int tor_h264_stream_header(int32_t width, int32_t height, uint8_t* out, int32_t cap);
 TOR_API int64_t tor_h264_frame_bytes(int32_t width, int32_t height);
+/* MP4Muxer.initialize + writeMP4_from + close (io/mp4.nim:113-163, driver trace_of_radiance_animation.nim:
+ * 203-210): reads the Annex-B stream src_annexb_path and writes an MP4 file with one avc1 video track --
+ * one sample per slice NAL unit, 90 kHz time base, 90000/fps ticks per sample (the reference: fps = 30).
+ * Host code, streams file to file.  Returns the number of samples written, or a negative status. */
+TOR_API int tor_mp4_mux_file(const char* src_annexb_path, const char* dst_mp4_path, int32_t width,
+                             int32_t height, int32_t fps);
 TOR_API int tor_encode_frame_device(TorContext* ctx, const double* d_pixels, int32_t nrows, int32_t ncols,
                                     uint8_t* d_slice, uint8_t* d_y, uint8_t* d_cb, uint8_t* d_cr,
                                     void* hip_stream);

@@ -115,3 +115,12 @@ def test_animation_driver_example_writes_a_valid_stream(tor, oracle, tmp_path):
     ocam, oobjs, _ = frames[0]
     canvas = oracle.render(h, w, spp, ocam, oobjs, seeding=0, math=1, arith=0).pixels
     assert data[len(hdr):len(hdr) + fb] == oracle.encode_frame(canvas)[4]
+    # ... and the driver muxed the stream into a.mp4 (MP4Muxer, trace_of_radiance_animation.nim:203-210): every
+    # slice is in there behind its 4-byte length (the box structure itself is tests/test_mp4.py's business)
+    mp4 = open(str(tmp_path / "a.mp4"), "rb").read()
+    assert mp4[4:8] == b"ftyp" and b"moov" in mp4 and b"avcC" in mp4
+    import struct
+    for k in range(len(frames)):
+        sl = data[len(hdr) + k * fb:len(hdr) + (k + 1) * fb]
+        body = sl[4:] if sl[:4] == b"\x00\x00\x00\x01" else sl[3:]
+        assert struct.pack(">I", len(body)) + body in mp4

@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
-    "tor_encode_frame_device", "tor_render_frame_h264", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -197,6 +197,7 @@ def lib():
                                           C.c_void_p, C.c_void_p]
     L.tor_render_frame_h264.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int64,
                                         C.POINTER(Options), C.POINTER(C.c_uint8), C.c_int64]
+    L.tor_mp4_mux_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
     L.tor_debug_accel_layout.argtypes = [HittableList, C.c_double, C.c_double, C.POINTER(C.c_int64), C.c_int64,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32)]
     L.tor_selftest_filter32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
@@ -504,6 +505,14 @@ class Context:
         st = Stats()
         _check(lib().tor_last_stats(self._h, C.byref(st)))
         return st
+
+
+def mp4_mux_file(src_annexb_path: str, dst_mp4_path: str, width: int, height: int, fps: int = 30) -> int:
+    """MP4Muxer (io/mp4.nim:113-163): Annex-B .264 -> .mp4; returns the number of samples."""
+    n = lib().tor_mp4_mux_file(os.fsencode(src_annexb_path), os.fsencode(dst_mp4_path), width, height, fps)
+    if n < 0:
+        raise TorError(n, lib().tor_last_error().decode())
+    return n
 
 
 def debug_accel_layout(world: HittableList, t_lo: float, t_hi: float):

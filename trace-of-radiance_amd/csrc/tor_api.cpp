@@ -42,6 +42,14 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+}  // namespace
+
+namespace tor {
+void set_last_error(const std::string& msg) { g_last_error = msg; }  // for the host-only sources (tor_mp4.cpp)
+}
+
+namespace {
+
 int fail_hip(hipError_t e, const char* what) {
   std::string m = std::string(what) + ": " + hipGetErrorString(e);
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
