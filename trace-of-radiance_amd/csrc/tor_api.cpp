@@ -158,10 +158,10 @@ struct TorContext {
   //   SAMPLE: 3 workgroups/CU (kernel compiled for <= 168 VGPRs)  -> best throughput
   //   PIXEL : 2 workgroups/CU (<= 256 VGPRs): a pixel is a sequential chain of spp samples, every
   //           wave that holds one must get good service
-  // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3|4), TOR_BLOCKS_PER_CU.
+  // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3), TOR_BLOCKS_PER_CU.
   int max_blocks_per_cu[2] = {2, 3};  // [seeding]
   int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
-  int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3|4): force a register-budget variant of the kernel
+  int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
 };
 
 namespace {
@@ -395,6 +395,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   }
   if (use_accel) {
     use_layout(ctx->d_accel[v32].always);
+    p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
     p.spatial_base = (int)hacc.spatial_base;
     p.shot = (const double*)ctx->d_accel[v32].hot.ptr;
     p.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
@@ -428,7 +429,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (cap < 1) cap = 4;
   if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
   const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
-  int bpc_eff = tor::integrate_blocks_per_cu(o.seeding, o.arith, waves_per_simd, (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0);
+  int bpc_eff = tor::integrate_blocks_per_cu(p, o.seeding, o.arith, waves_per_simd);
   if (bpc_eff > cap) bpc_eff = cap;
   const long long resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
@@ -471,7 +472,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
   HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, &ctx->cam_host[slot], sizeof(TorCamera), hipMemcpyHostToDevice, stream));
   if (use_accel) {
-    p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);
     HIP_TRY(hipMemcpyAsync((void*)p.bnd, bnd_host.data(), bnd_host.size() * 8, hipMemcpyHostToDevice, stream));
   }
   HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));

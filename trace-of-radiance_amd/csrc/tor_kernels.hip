@@ -107,8 +107,9 @@ constexpr int kTilePixels = 64;  // SEED_PIXEL work unit: one wave-load of conse
 constexpr int kAccSlots = 16;  // per-wave LDS pixel-accumulator cache (TOR_SEED_SAMPLE)
 static_assert(kBlock == kPad, "hot-record padding must equal the candidate block size");
 
-// LDS per wave: queue (kQCap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag))
-constexpr int kWaveLdsBytes = kQCap * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4;
+// LDS per wave: queue (kQCap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
+constexpr int kProfSlots = 8;   // debug counters of the wave log (u64): 5 section sums, trips, spare, last time stamp
+constexpr int kWaveLdsBytes = kQCap * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8;
 static_assert(kWaveLdsBytes % 16 == 0, "keep LDS carve-outs 16-byte aligned");
 
 // The camera (24 float64) is needed once per new path only; read it there instead of keeping
@@ -137,7 +138,7 @@ __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
   return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
 }
 
-template <int SEEDING, int ARITH, int WAVES_PER_SIMD, int F32>
+template <int SEEDING, int ARITH, int WAVES_PER_SIMD, int F32, int BLOCKS>
 __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
   double* acc_lds = reinterpret_cast<double*>(wave_lds + kQCap * 64 * 4);          // [kAccSlots][3]
   int* tag_lds = reinterpret_cast<int*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 24);  // [kAccSlots]
+  unsigned long long* prof_lds = reinterpret_cast<unsigned long long*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 28);
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
   // TOR_ACCEL_BLOCKS: the block expansion gathers 8 x 64 B per lane and trip with 64 different
   // addresses; when the compact records fit they are staged in LDS once per workgroup.
-  const bool staged = p.shot_lds_doubles > 0 || p.shot32_lds_floats > 0;
+  const bool staged = BLOCKS && (p.shot_lds_doubles > 0 || p.shot32_lds_floats > 0);
   double* stage = reinterpret_cast<double*>(smem_raw + (kThreads / 64) * kWaveLdsBytes);
   const ldptr shot_lds = (ldptr)stage;
   // (a launch stages either the float64 compact records or the float32 pair records)
@@ -200,18 +202,20 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
   const unsigned long long t_start = (p.wave_log != nullptr) ? wall_clock64() : 0ull;
   unsigned long long t_exh = 0, it_exh = 0;
-  unsigned st_trips = 0;  // debug: trips of the deferred resolve loop (wave level)
-  // debug (wave_log only): shader-clock cycles per section of the bounce iteration
+  // debug (wave_log only): shader-clock cycles per section of the bounce iteration and trips of the resolve
+  // loop, kept in LDS (lane 0) so that the counters cost no registers when they are off
   const bool prof = p.wave_log != nullptr;
-  unsigned long long sec_refill = 0, sec_loop = 0, sec_resolve = 0, sec_shade = 0, sec_deposit = 0, sec_mark = 0;
-  const unsigned long long sec_begin = prof ? __builtin_readcyclecounter() : 0ull;
-#define TOR_SEC(acc)                                        \
-  if (prof) {                                               \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    acc += now_ - sec_mark;                                 \
-    sec_mark = now_;                                        \
+  enum { kSecRefill = 0, kSecLoop, kSecResolve, kSecShade, kSecDeposit, kSecTrips, kSecBegin, kSecMark };
+  if (prof && lane == 0) {
+    for (int k = 0; k < kProfSlots; ++k) prof_lds[k] = 0;
+    prof_lds[kSecBegin] = prof_lds[kSecMark] = __builtin_readcyclecounter();
   }
-  sec_mark = sec_begin;
+#define TOR_SEC(slot)                                             \
+  if (prof && lane == 0) {                                        \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_lds[slot] += now_ - prof_lds[kSecMark];                  \
+    prof_lds[kSecMark] = now_;                                    \
+  }
 
   for (;;) {
     // ================= (A) refill lanes that have no live path =========================
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       depth = 0;
       active = true;
     }
-    TOR_SEC(sec_refill)
+    TOR_SEC(kSecRefill)
     const unsigned long long active_mask = ballot64(active);
     if (active_mask == 0) {
       if (exhausted) break;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
               }
             }
-          } else if (seg_kind == 3 || seg_kind == 4) {
+          } else if (BLOCKS && (seg_kind == 3 || seg_kind == 4)) {
             // TOR_ACCEL_BLOCKS: the records are inflated axis-aligned boxes around spatial blocks of 8
             // objects (kind 3, entries flagged with bit 31) or around 8 such blocks (kind 4, bit 30).
             // Slab test; a set bit means 'this lane has to look inside'.  1/d may be +-inf (d = 0): (lo - o) * inf is +-inf, or
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           i = 0;
         }
 
-        TOR_SEC(sec_loop)
+        TOR_SEC(kSecLoop)
         // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
         // Queue entries are 8-bit masks over 8 consecutive cold slots (direct candidates) or, flagged
         // with bit 31, over 8 block bounds.  A trip of the loop handles one set bit per lane: either
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         };
         // TOR_ACCEL_F32 block expansion: the spatial movers share one time group
         SegF32 sp32{};
-        if (F32 && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
+        if (F32 && BLOCKS && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
         unsigned kq = 0, cur_mask = 0, cur_block = 0, cur_is_bound = 0;
         for (;;) {
           if (cur_mask == 0 && kq < qn) {
@@ -587,12 +591,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
           const bool has = cur_mask != 0;
           if (ballot64(has) == 0) break;
-          st_trips += 1;
+          if (prof && lane == 0) prof_lds[kSecTrips] += 1;
           if (has) {
             const int b = 31 - __builtin_clz(cur_mask);  // bit (7 - j) <-> record j of the group
             cur_mask &= ~(1u << b);
             const unsigned rec = cur_block * kBlock + (unsigned)(7 - b);
-            if (cur_is_bound) {
+            if (BLOCKS && cur_is_bound) {
               // ---- spatial block `blk_id`: filter its 8 objects, then exact roots for the survivors
               auto expand = [&](auto blk, auto HS, unsigned blk_id) {
                 constexpr int hs = decltype(HS)::value;
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             }
           }
         }
-        TOR_SEC(sec_resolve)
+        TOR_SEC(kSecResolve)
         if (!full) break;
       }
 
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       }
     }
 
-    TOR_SEC(sec_shade)
+    TOR_SEC(kSecShade)
     if (SEEDING == 1) {
       // ---- deposit finished samples: exact (2^-36-quantised) float64 sums, any order ------
       // The wave keeps the pixels it is currently filling in a small LDS cache (pixels arrive
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         ended_mask &= ~ballot64(mine);
       }
     }
-    TOR_SEC(sec_deposit)
+    TOR_SEC(kSecDeposit)
   }
 #undef TOR_SEC
 
@@ -833,12 +837,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       unsigned long long* w = p.wave_log + (size_t)(blockIdx.x * (kThreads / 64) + wave) * 8;
       w[0] = t_start; w[1] = wall_clock64(); w[2] = st_iters;
       w[3] = st_queries | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
-      w[4] = t_exh; w[5] = (it_exh & 0xffffffffull) | ((unsigned long long)st_trips << 32);
+      w[4] = t_exh; w[5] = (it_exh & 0xffffffffull) | (prof_lds[kSecTrips] << 32);
       // six 21-bit fields in units of 4096 shader cycles: refill+camera, object loop, exact resolve | shade, deposit, total
-      const unsigned long long total = __builtin_readcyclecounter() - sec_begin;
+      const unsigned long long total = __builtin_readcyclecounter() - prof_lds[kSecBegin];
       auto f21 = [](unsigned long long c) { c >>= 12; return c > 0x1fffffull ? 0x1fffffull : c; };
-      w[6] = f21(sec_refill) | (f21(sec_loop) << 21) | (f21(sec_resolve) << 42);
-      w[7] = f21(sec_shade) | (f21(sec_deposit) << 21) | (f21(total) << 42);
+      w[6] = f21(prof_lds[kSecRefill]) | (f21(prof_lds[kSecLoop]) << 21) | (f21(prof_lds[kSecResolve]) << 42);
+      w[7] = f21(prof_lds[kSecShade]) | (f21(prof_lds[kSecDeposit]) << 21) | (f21(total) << 42);
     }
     if (lane == 0) {
       atomicAdd(p.stats + 0, st_queries);
@@ -966,33 +970,36 @@ __global__ void selftest_kernel(int op, const double* x, const double* y, double
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from tor_api.cpp)
 // ---------------------------------------------------------------------------------------
-// variant table: [seeding 0|1][arith 0|1][W 2|3|4][f32 0|1]; the TOR_ACCEL_F32 variants exist for the
-// 2- and 3-workgroup launch shapes only
+// variant table: [seeding 0|1][arith 0|1][W 2|3][f32 0|1][blocks 0|1].  The block-expansion code (an unrolled
+// 8-object stage per lane) is what makes the 168-register variants spill; launches without TOR_ACCEL_BLOCKS
+// use kernels compiled without it (no scratch traffic at all).
 typedef void (*IntegrateFn)(const KParams);
-static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32) {
-#define TOR_V(S, A, W, F) if (seeding == S && arith == A && w == W && f32 == F) return integrate_kernel<S, A, W, F>;
-  TOR_V(0, 0, 2, 0) TOR_V(0, 1, 2, 0) TOR_V(1, 0, 2, 0) TOR_V(1, 1, 2, 0)
-  TOR_V(0, 0, 3, 0) TOR_V(0, 1, 3, 0) TOR_V(1, 0, 3, 0) TOR_V(1, 1, 3, 0)
-  TOR_V(0, 0, 4, 0) TOR_V(0, 1, 4, 0) TOR_V(1, 0, 4, 0) TOR_V(1, 1, 4, 0)
-  TOR_V(0, 0, 2, 1) TOR_V(0, 1, 2, 1) TOR_V(1, 0, 2, 1) TOR_V(1, 1, 2, 1)
-  TOR_V(0, 0, 3, 1) TOR_V(0, 1, 3, 1) TOR_V(1, 0, 3, 1) TOR_V(1, 1, 3, 1)
+static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32, int blocks) {
+#define TOR_V(S, A, W, F, B) if (seeding == S && arith == A && w == W && f32 == F && blocks == B) return integrate_kernel<S, A, W, F, B>;
+#define TOR_V4(S, A, W) TOR_V(S, A, W, 0, 0) TOR_V(S, A, W, 0, 1) TOR_V(S, A, W, 1, 0) TOR_V(S, A, W, 1, 1)
+  TOR_V4(0, 0, 2) TOR_V4(0, 1, 2) TOR_V4(1, 0, 2) TOR_V4(1, 1, 2)
+  TOR_V4(0, 0, 3) TOR_V4(0, 1, 3) TOR_V4(1, 0, 3) TOR_V4(1, 1, 3)
+  TOR_V4(2, 0, 3)   // cost probe of the SEED_PIXEL tile schedule
+#undef TOR_V4
 #undef TOR_V
   return nullptr;
 }
 
-static int clamp_w(int waves_per_simd, int f32) {
-  // register budget follows the launch shape: 2 workgroups/CU -> 256 VGPRs, 3 -> 168, 4 -> 128
-  int w = waves_per_simd <= 2 ? 2 : (waves_per_simd == 3 ? 3 : 4);
-  if (f32 && w > 3) w = 3;
-  return w;
+static int clamp_w(int waves_per_simd) {
+  // register budget follows the launch shape: 2 workgroups/CU -> 256 VGPRs, 3 (or more) -> 168
+  return waves_per_simd <= 2 ? 2 : 3;
+}
+
+static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
+static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? 1 : 0; }
+static size_t dynamic_lds(const KParams& p) {
+  return (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4;
 }
 
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4;
-  if (p.hot32 != nullptr || p.shot32 != nullptr)
-    hipLaunchKernelGGL((integrate_kernel<2, 0, 3, 1>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
-  else
-    hipLaunchKernelGGL((integrate_kernel<2, 0, 3, 0>), dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  IntegrateFn fn = integrate_variant(2, 0, 3, wants_f32(p), wants_blocks(p));
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p), stream, p);
   return hipGetLastError();
 }
 
@@ -1003,19 +1010,16 @@ hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles,
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream) {
-  const int f32 = (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0;
-  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd, f32), f32);
+  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
   if (!fn) return hipErrorInvalidValue;
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4;
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), smem, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p), stream, p);
   return hipGetLastError();
 }
 
-int integrate_blocks_per_cu(int seeding, int arith, int waves_per_simd, int f32) {
-  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd, f32), f32);
-  const size_t smem = (size_t)kWaveLdsBytes * (kThreads / 64);
+int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_per_simd) {
+  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
   int n = 0;
-  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, smem) != hipSuccess || n < 1) n = 1;
+  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, dynamic_lds(p)) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
