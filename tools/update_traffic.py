@@ -1,0 +1,65 @@
+"""Rebuild profiles/traffic.json (what bench.py reports as roofline.traffic / roofline.executed) from the
+committed rocprofv3 summaries, so the numbers cannot drift from the evidence.
+
+    python tools/update_traffic.py
+"""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = {   # key in traffic.json -> (summary file, seeding template argument)
+    "1920x1080x100:sample:strict": ("r1_final_summary.txt", 1),
+    "1920x1080x100:pixel:strict": ("r1_final_pixel_summary.txt", 0),
+    "1920x1080x100:sample:strict:f32": ("r1_accel_f32_summary.txt", 1),
+    "1920x1080x100:sample:strict:blocks": ("r1_accel_blocks_summary.txt", 1),
+    "1920x1080x100:sample:strict:blocks+f32": ("r1_accel_blocks_f32_summary.txt", 1),
+}
+
+
+def counters(path, seeding):
+    out = {}
+    pat = re.compile(r"integrate_kernel<%d, .*?\| (\w+) \| \d+ \| ([0-9.e+]+) \| ([0-9.]+)" % seeding)
+    for line in open(path):
+        m = pat.search(line)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+            out.setdefault("_ms", float(m.group(3)))
+    return out
+
+
+def main():
+    res = {"_note": "HBM bytes per integrate_kernel launch and executed-instruction counters from rocprofv3 PMC passes "
+                    "(separate --pmc runs, one launch each; profiles/*_summary.txt; regenerate with tools/update_traffic.py). "
+                    "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read; "
+                    "WRITE_SIZE uncorrected). simd_cycles = GRBM_GUI_ACTIVE (summed over the 8 XCDs) * 128 SIMDs per XCD."}
+    for key, (fname, seeding) in CONFIGS.items():
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        c = counters(path, seeding)
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        e = {"fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
+             "bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0}
+        if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+            simd = c["GRBM_GUI_ACTIVE"] * 128.0
+            ex = {"valu_wave_instructions": c["SQ_INSTS_VALU"],
+                  "valu_active_quad_cycles": c.get("SQ_ACTIVE_INST_VALU"),
+                  "simd_cycles": simd,
+                  "valu_active_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / simd, 4) if "SQ_ACTIVE_INST_VALU" in c else None,
+                  "fp64_add_mul_fma_wave_instructions": sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64")),
+                  "f32_add_mul_fma_wave_instructions": sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")),
+                  "scalar_cache_hit_rate": round(c["SQC_DCACHE_HITS"] / (c["SQC_DCACHE_HITS"] + c["SQC_DCACHE_MISSES"]), 4) if "SQC_DCACHE_MISSES" in c else None,
+                  "source": "profiles/" + fname}
+            e["executed"] = ex
+        res[key] = e
+    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    for k, v in res.items():
+        if k != "_note":
+            print(k, {a: b for a, b in v.items() if a != "executed"}, (v.get("executed") or {}).get("valu_active_frac"))
+
+
+if __name__ == "__main__":
+    main()

@@ -601,11 +601,17 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               auto expand = [&](auto blk, auto HS, unsigned blk_id) {
                 constexpr int hs = decltype(HS)::value;
                 unsigned m8 = 0;
-#pragma unroll
-                for (int j = 0; j < kBlock; ++j) {
+                auto test = [&](int j) {
                   double cx, cy, cz, f;
                   spatial_center(blk + hs * j, HS, cx, cy, cz, f);
                   m8 = push_bit(m8, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, blk[hs * j + 3]));
+                };
+                if constexpr (hs == 4) {  // 32-byte static records: all eight in flight
+#pragma unroll
+                  for (int j = 0; j < kBlock; ++j) test(j);
+                } else {  // 64-byte records: four at a time (eight make the 168-register variants spill inside the bounce loop)
+#pragma unroll 4
+                  for (int j = 0; j < kBlock; ++j) test(j);
                 }
                 while (m8 != 0) {
                   const int bb = 31 - __builtin_clz(m8);
@@ -620,7 +626,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               auto expand32 = [&](auto blk, auto ST, unsigned blk_id) {
                 constexpr int st = decltype(ST)::value;
                 unsigned m8 = 0;
-#pragma unroll
+                // two pairs at a time: with all four in flight the 168-register variants spill inside the bounce loop
+#pragma unroll 2
                 for (int j = 0; j < kBlock / 2; ++j) {
                   auto r = blk + st * j;
                   const f2v c0x = {r[0], r[1]}, c0y = {r[2], r[3]}, c0z = {r[4], r[5]};
