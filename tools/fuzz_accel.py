@@ -1,0 +1,77 @@
+"""Differential fuzz of the exact accelerations on the GPU: random scenes and cameras, every accel mode against the
+float64 brute-force canvas, bit for bit.  Usage: python tools/fuzz_accel.py [seconds] [seed]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+tor = importlib.import_module("trace-of-radiance_amd")
+
+
+def random_scene(rng):
+    n = int(rng.choice([40, 90, 200, 485, 700, 1300]))
+    spread = float(rng.choice([0.02, 1.0, 4.0, 12.0, 60.0, 3000.0]))
+    shift = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 10.0, 1e3, 1e5]))
+    rscale = spread / 12.0
+    groups = [(0.0, 1.0), (-0.5, 0.5), (0.25, 2.0), (1.0, 0.0)][: int(rng.integers(1, 5))]
+    recs = []
+    if rng.random() < 0.6:
+        R = float(rng.choice([100.0, 1000.0])) * rscale
+        recs.append([0, shift[0], shift[1] - R, shift[2], shift[0], shift[1] - R, shift[2], 0, 1, R, 0, .5, .5, .5, 0, 0])
+    mover_frac = float(rng.choice([0.0, 0.5, 0.9]))
+    general = rng.random() < 0.4
+    while len(recs) < n:
+        c = shift + np.array([rng.uniform(-spread, spread), rng.uniform(0, 0.3 * spread), rng.uniform(-spread, spread)])
+        r = float(rng.choice([0.15, 0.2, 0.3, 0.45, 1.0])) * rscale * (1 if rng.random() > 0.03 else -1)
+        mat = int(rng.integers(0, 3))
+        alb = rng.uniform(0.1, 0.95, 3)
+        fuzz, ri = rng.uniform(0, 0.6), rng.uniform(1.2, 1.8)
+        if rng.random() >= mover_frac:
+            recs.append([0, *c, *c, 0, 1, r, mat, *alb, fuzz, ri])
+        else:
+            t0, t1 = groups[int(rng.integers(0, len(groups)))]
+            d = rng.uniform(-0.6, 0.6, 3) * rscale if general else np.array([0.0, rng.uniform(0, 0.6) * rscale, 0.0])
+            recs.append([1, *c, *(c + d), t0, t1, r, mat, *alb, fuzz, ri])
+    recs = np.asarray(recs, dtype=np.float64)
+    inside = rng.random() < 0.3
+    look_from = shift + (rng.uniform(-0.5, 0.5, 3) * spread + (0, 0.2 * spread, 0) if inside
+                         else np.array([1.8, 0.7, 1.1]) * spread * rng.uniform(0.6, 2.0))
+    shutter = [(0.0, 1.0), (-1.0, 3.0), (0.5, 0.5), (2.0, 1.0), (0.0, 0.0)][int(rng.integers(0, 5))]
+    cam = tor.camera(look_from=tuple(look_from), look_at=tuple(shift + (0, 0.1 * spread, 0)),
+                     vertical_field_of_view=float(rng.uniform(15, 80)), aperture=float(rng.uniform(0, 0.3)) * rscale,
+                     focus_distance=float(rng.uniform(0.5, 2) * spread), shutter_open=shutter[0], shutter_close=shutter[1])
+    return recs, cam
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    t0 = time.time()
+    n_scenes = n_renders = bad = 0
+    while time.time() - t0 < budget:
+        recs, cam = random_scene(rng)
+        scene = tor.Scene.from_records(recs)
+        h, w = int(rng.choice([16, 24, 40])), int(rng.choice([26, 34, 64]))
+        spp, depth = int(rng.choice([2, 6, 33])), int(rng.choice([3, 12, 50]))
+        for seeding in (0, 1):
+            canv = []
+            for accel in (0, 1, 2, 3):
+                cv = tor.new_canvas(h, w, spp, 2.2)
+                tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, accel=accel))
+                canv.append(cv.pixels.copy())
+                n_renders += 1
+            for accel in (1, 2, 3):
+                if not np.array_equal(canv[0], canv[accel], equal_nan=True):
+                    bad += 1
+                    print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} accel {accel}: "
+                          f"{int((canv[0] != canv[accel]).sum())} values differ", flush=True)
+        n_scenes += 1
+    print(f"fuzz: {n_scenes} scenes, {n_renders} renders, {bad} mismatches in {time.time() - t0:.0f} s", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
