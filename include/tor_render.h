@@ -154,7 +154,10 @@ enum {
 /* Replaces `proc render*(canvas: var Canvas, cam: Camera, world: HittableList,
  * max_depth: int)` -- render.nim:49.  Blocking: canvas.pixels is complete on return (the
  * reference's canvas is complete only after exit(Weave)/syncRoot(Weave),
- * trace_of_radiance.nim:61-63).  Reference semantics: TOR_SEED_PIXEL, TOR_ARITH_STRICT. */
+ * trace_of_radiance.nim:61-63).  Reference semantics: TOR_SEED_PIXEL, TOR_ARITH_STRICT.
+ * Wherever options are NULL / absent, the environment variable TOR_DEFAULT_ACCEL (0..3, TOR_ACCEL_* bits)
+ * selects the exact accelerations -- a speed knob for hosts that keep the reference's signature; the
+ * canvas is bit-identical for every value. */
 TOR_API int tor_render(TorCanvas* canvas, const TorCamera* cam, TorHittableList world,
                        int64_t max_depth);
 

@@ -496,3 +496,19 @@ def test_accel_fuzz_short(tor):
     r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_accel.py"), "15", "2026"], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-2000:]
     assert b"0 mismatches" in r.stdout
+
+
+def test_default_accel_from_environment(tor, monkeypatch):
+    """tor_render() keeps the reference's signature (no options); TOR_DEFAULT_ACCEL opts it into the exact
+    accelerations.  Same canvas, and explicit options are never overridden."""
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+
+    def plain():
+        cv = tor.new_canvas(27, 48, 4, 2.2)
+        tor.render(cv, cam, scene.list(), 50)            # options=None -> tor_render(), the reference's signature
+        return cv.pixels.copy()
+    monkeypatch.delenv("TOR_DEFAULT_ACCEL", raising=False)
+    base = plain()
+    for v in ("3", "2", "1", "17", "x"):
+        monkeypatch.setenv("TOR_DEFAULT_ACCEL", v)
+        assert np.array_equal(plain(), base), v

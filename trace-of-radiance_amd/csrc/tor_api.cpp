@@ -178,6 +178,12 @@ bool valid_options(const TorOptions* opt, TorOptions& o) {
   if (opt) {
     if (opt->struct_size != sizeof(TorOptions)) return false;
     o = *opt;
+  } else if (const char* e = std::getenv("TOR_DEFAULT_ACCEL")) {
+    // tor_render() has the reference's signature and no options: a host that cannot pass TorOptions (the Nim
+    // shim of INTEGRATION.md) opts into the exact accelerations through the environment.  They never change a
+    // pixel, so this is a speed knob only.
+    const int v = std::atoi(e);
+    if (v >= 0 && v <= (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) o.accel = v;
   }
   if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return false;
   if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return false;
