@@ -157,9 +157,10 @@ struct TorContext {
   // extra waves add little throughput and park work in slow waves.  Per seeding mode:
   //   SAMPLE: 3 workgroups/CU (kernel compiled for <= 168 VGPRs)  -> best throughput
   //   PIXEL : 2 workgroups/CU (<= 256 VGPRs): a pixel is a sequential chain of spp samples, every
-  //           wave that holds one must get good service
+  //           wave that holds one must get good service; with an exact acceleration the iteration is short
+  //           enough that 3 workgroups/CU win (C2: f32 1768 -> 1900, blocks 1625 -> 1790, both 2133 -> 2350)
   // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3), TOR_BLOCKS_PER_CU.
-  int max_blocks_per_cu[2] = {2, 3};  // [seeding]
+  int max_blocks_per_cu[2][2] = {{2, 3}, {3, 3}};  // [seeding][any TOR_ACCEL_* bit set]
   int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
   int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
 };
@@ -226,7 +227,8 @@ int tor_context_create(int32_t device, TorContext** out) {
   ctx->num_cus = prop.multiProcessorCount;
   if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
   if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
-  if (const char* b = std::getenv("TOR_BLOCKS_PER_CU")) ctx->max_blocks_per_cu[0] = ctx->max_blocks_per_cu[1] = std::atoi(b);
+  if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
+    for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
   e = ctx->counters.ensure(8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kEventRing * sizeof(TorCamera));
   for (int i = 0; i < TorContext::kEventRing && e == hipSuccess; ++i) {
@@ -424,14 +426,14 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
     int& wg = stage_wg;
     wg = 0;
-    for (int tryw = ctx->max_blocks_per_cu[o.seeding]; tryw >= 2 && wg == 0; --tryw)
+    for (int tryw = ctx->max_blocks_per_cu[o.seeding][o.accel != 0]; tryw >= 2 && wg == 0; --tryw)
       if (hot_bytes <= hard_cap && hot_bytes + 18432 <= (size_t)(160 * 1024) / (size_t)tryw - 1024) wg = tryw;
     p.shot_lds_doubles = (wg > 0 && !p.shot32) ? (int)hacc.hot.size() : 0;
     p.shot32_lds_floats = (wg > 0 && p.shot32) ? (int)hacc.hot32.size() : 0;
   }
   // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
   // kernel variant's register budget follows it
-  int cap = ctx->max_blocks_per_cu[o.seeding];
+  int cap = ctx->max_blocks_per_cu[o.seeding][o.accel != 0];
   if (cap < 1) cap = 4;
   if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
   const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
