@@ -306,6 +306,12 @@ TOR_API int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_
 TOR_API int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d,
                                      const double* time, int8_t* keep);
 
+/* Float32 slab test of the culling boxes on the HOST (same source as the kernel): ray i against the box [lo_i, hi_i].
+ * keep[i] = the float32 test keeps the box, need[i] = the float64 slab test of the float64 path passes.
+ * Correct iff need[i] != 0 implies keep[i] != 0. */
+TOR_API int tor_selftest_slab32_host(int64_t n, const double* o, const double* d, const double* lo, const double* hi,
+                                     const double* origin, int32_t* keep, int32_t* need);
+
 /* TOR_ACCEL_F32 self test on the HOST (same source as the kernel's pre-filter): ray i against sphere i with
  * centre c0 + dc * f (moving != 0) or c0.  keep[i] = pre-filter keeps the object; need[i] bit 0 = the
  * float64 test D > 0 and (half_b < 0 or c < 0) holds, bit 1 = the reference's hit() accepts a root.

@@ -164,3 +164,45 @@ def test_scene_walk_keeps_every_needed_object(tor, which):
     assert needed > R // 2
     if which != "far_objects":   # rays that start 1500 units out are beyond float32's resolution: kept, not wrong
         assert extra < 0.06 * needed + 20, (extra, needed)
+
+
+@pytest.mark.parametrize("scale,origin", [(12.0, (0.0, 0.0, 0.0)), (300.0, (1000.0, -2000.0, 500.0)), (0.01, (0.0, 0.0, 0.0)),
+                                          (2e4, (5.0, 5.0, 5.0))])
+def test_slab32_never_drops_a_box_the_float64_test_enters(tor, scale, origin):
+    """The float32 slab test of the culling boxes (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32), host build of the kernel's
+    source: rays through box corners / edges / faces (grazing to float32 resolution), origins inside and on the
+    faces, axis-parallel directions (1/d = inf), tiny components.  It may keep more, never less."""
+    rng = np.random.default_rng(int(scale * 7) + 3)
+    origin = np.asarray(origin, dtype=np.float64)
+    n = 400_000
+    c = origin + rng.uniform(-scale, scale, (n, 3))
+    half = rng.uniform(0.01, 0.2, (n, 3)) * scale
+    lo, hi = c - half, c + half
+    o = origin + rng.uniform(-1.5 * scale, 1.5 * scale, (n, 3))
+    kind = rng.integers(0, 6, n)
+    # target: a point on the box surface (corner / edge / face), nudged in or out by a relative eps
+    pick = rng.integers(0, 3, (n, 3))                                   # 0 -> lo, 1 -> hi, 2 -> interior coordinate
+    tgt = np.where(pick == 0, lo, np.where(pick == 1, hi, c + rng.uniform(-1, 1, (n, 3)) * half))
+    eps = np.where(kind == 0, rng.uniform(-1e-3, 1e-3, n), np.where(kind == 1, rng.choice([-1e-7, -1e-9, 0.0, 1e-9, 1e-7], n), 0.0))
+    tgt = c + (tgt - c) * (1.0 + eps)[:, None]
+    inside = kind == 2
+    o[inside] = c[inside] + rng.uniform(-1, 1, (int(inside.sum()), 3)) * half[inside]
+    onface = kind == 3
+    o[onface] = tgt[onface]
+    d = tgt - o
+    d[onface | inside] = rng.normal(size=(int((onface | inside).sum()), 3))
+    axis = kind == 4                                                    # axis-parallel: two components exactly 0
+    k = rng.integers(0, 3, n)
+    for a in range(3):
+        z = axis & (k != a)
+        d[z, a] = 0.0
+    tiny = kind == 5
+    d[tiny, 0] *= 1e-12
+    d *= rng.choice([1.0, 1e-3, 40.0], (n, 1))
+    keep, need = tor.selftest_slab32(o, d, lo, hi, origin)
+    missed = np.flatnonzero((need != 0) & (keep == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]], lo[missed[:1]], hi[missed[:1]])
+    assert 0.2 * n < np.count_nonzero(need) < 0.95 * n
+    if scale <= 300.0:   # it is a real filter: clearly missed boxes are dropped
+        far_miss = (need == 0) & (kind == 0) & (eps > 5e-4) & (np.abs(pick - 1).sum(1) < 3)
+        assert np.count_nonzero(keep[(need == 0)]) < 0.5 * np.count_nonzero(need == 0)

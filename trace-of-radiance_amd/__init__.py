@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
-    "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_slab32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
 ]
 
@@ -202,6 +202,7 @@ def lib():
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32)]
     L.tor_selftest_filter32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
         [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2
+    L.tor_selftest_slab32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int32)] * 2
     L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
@@ -547,6 +548,20 @@ def selftest_filter32(o, d, c0, dc, moving, f, r2, origin):
                                             dc.ctypes.data_as(P), moving.ctypes.data_as(I), f.ctypes.data_as(P),
                                             r2.ctypes.data_as(P), origin.ctypes.data_as(P), keep.ctypes.data_as(I),
                                             need.ctypes.data_as(I)))
+    return keep, need
+
+
+def selftest_slab32(o, d, lo, hi, origin):
+    """(keep, need) int32 arrays: host build of the float32 box test vs the float64 slab test."""
+    dp = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    o, d, lo, hi, origin = dp(o), dp(d), dp(lo), dp(hi), dp(origin)
+    n = len(o)
+    keep = np.zeros(n, dtype=np.int32)
+    need = np.zeros(n, dtype=np.int32)
+    P = C.POINTER(C.c_double)
+    I = C.POINTER(C.c_int32)
+    _check(lib().tor_selftest_slab32_host(n, o.ctypes.data_as(P), d.ctypes.data_as(P), lo.ctypes.data_as(P), hi.ctypes.data_as(P),
+                                          origin.ctypes.data_as(P), keep.ctypes.data_as(I), need.ctypes.data_as(I)))
     return keep, need
 
 

@@ -143,6 +143,7 @@ struct TorContext {
   // host-side staging of the per-launch data: it must outlive the asynchronous copies
   TorCamera cam_host[64];
   std::vector<double> bnd_host[64];
+  std::vector<float> bnd32_host[64];
   DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
   DeviceBuffer slice;     // tor_render_frame_h264's device slice buffer
   bool collect_stats = false;
@@ -312,7 +313,8 @@ int tor_scene_upload(TorContext* ctx, TorHittableList world) {
       }
       const size_t n_bnd_p = (ctx->accel[v].n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
       const size_t n_super_p = (n_bnd_p / tor::kPad + tor::kPad - 1) / tor::kPad * tor::kPad;
-      ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * 8;
+      // per slot: the float64 boxes, then the same records as float32 (8 floats each)
+      ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * (8 + 4);
       HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
     }
   }
@@ -421,15 +423,27 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     // float32 pair records (TOR_ACCEL_F32; survivors are re-tested from the cold records -- staging the float64
     // records as well measured +2 % at best) or the float64 compact records.  It must fit at this mode's
     // workgroups/CU, else one workgroup fewer, else global loads.
-    const size_t hot_bytes = p.shot32 ? hacc.hot32.size() * 4 : hacc.hot.size() * 8;
+    size_t hot_bytes = p.shot32 ? hacc.hot32.size() * 4 : hacc.hot.size() * 8;
+    size_t bnd32_stage_floats = 0;
+    if (p.shot32) {
+      // float32 boxes for the slab tests; on two-level scenes the lanes read the block boxes themselves: stage them
+      p.sp_bmax = tor::block_bounds_f32(bnd_host, ctx->f32.origin, ctx->bnd32_host[slot]);
+      p.bnd32 = (const float*)((const char*)p.bnd + bnd_host.size() * 8);
+      if (hacc.two_level) bnd32_stage_floats = 8 * ((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad);
+    }
     const char* st = std::getenv("TOR_STAGE_LDS");
     const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
     int& wg = stage_wg;
     wg = 0;
+    auto fits = [&](size_t bytes, int wgs) {
+      return bytes <= hard_cap && bytes + 18432 <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
+    };
     for (int tryw = ctx->max_blocks_per_cu[o.seeding][o.accel != 0]; tryw >= 2 && wg == 0; --tryw)
-      if (hot_bytes <= hard_cap && hot_bytes + 18432 <= (size_t)(160 * 1024) / (size_t)tryw - 1024) wg = tryw;
+      if (fits(hot_bytes, tryw)) wg = tryw;
     p.shot_lds_doubles = (wg > 0 && !p.shot32) ? (int)hacc.hot.size() : 0;
     p.shot32_lds_floats = (wg > 0 && p.shot32) ? (int)hacc.hot32.size() : 0;
+    // the block boxes ride along only if they do not cost a workgroup per CU
+    p.bnd32_lds_floats = (wg > 0 && p.shot32 && fits(hot_bytes + bnd32_stage_floats * 4, wg)) ? (int)bnd32_stage_floats : 0;
   }
   // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
   // kernel variant's register budget follows it
@@ -481,6 +495,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, &ctx->cam_host[slot], sizeof(TorCamera), hipMemcpyHostToDevice, stream));
   if (use_accel) {
     HIP_TRY(hipMemcpyAsync((void*)p.bnd, bnd_host.data(), bnd_host.size() * 8, hipMemcpyHostToDevice, stream));
+    if (p.bnd32)
+      HIP_TRY(hipMemcpyAsync((void*)p.bnd32, ctx->bnd32_host[slot].data(), ctx->bnd32_host[slot].size() * 4, hipMemcpyHostToDevice, stream));
   }
   HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
   if (o.seeding == TOR_SEED_PIXEL && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && n_tiles > 1) {
@@ -828,6 +844,38 @@ int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double
         }
       }
     }
+  }
+  return TOR_OK;
+}
+
+// Float32 slab test of the culling boxes on the HOST (same source as the kernel): ray i against box i.
+// keep[i] = slab_bit32 on the float32 record block_bounds_f32 makes of the box; need[i] = the float64 slab test
+// of the kernel's float64 path on the same box.  Correct iff need implies keep.
+int tor_selftest_slab32_host(int64_t n, const double* o, const double* d, const double* lo, const double* hi,
+                             const double* origin, int32_t* keep, int32_t* need) {
+  if (n < 0 || !o || !d || !lo || !hi || !origin || !keep || !need)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_slab32_host: bad argument");
+  std::vector<double> bnd((size_t)n * 8, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { bnd[8 * i + k] = lo[3 * i + k]; bnd[8 * i + 3 + k] = hi[3 * i + k]; }
+  std::vector<float> bnd32;
+  const float bmax = tor::block_bounds_f32(bnd, origin, bnd32);
+  using tor::f2v;
+  for (int64_t i = 0; i < n; ++i) {
+    const double* oo = o + 3 * i; const double* dd = d + 3 * i;
+    const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+    const tor::RayF32 r = tor::make_ray_f32(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a, origin[0], origin[1], origin[2]);
+    const tor::BoxRay32 b = tor::make_box_ray32(r, bmax);
+    const float* rec = &bnd32[8 * (size_t)i];
+    keep[i] = (int32_t)(tor::slab_bit32(b, (f2v){rec[0], rec[1]}, (f2v){rec[2], rec[3]}, (f2v){rec[4], rec[5]}) | (r.wild & 1u));
+    const double ix = 1.0 / dd[0], iy = 1.0 / dd[1], iz = 1.0 / dd[2];
+    const double* c = &bnd[8 * (size_t)i];
+    const double tx0 = (c[0] - oo[0]) * ix, tx1 = (c[3] - oo[0]) * ix;
+    const double ty0 = (c[1] - oo[1]) * iy, ty1 = (c[4] - oo[1]) * iy;
+    const double tz0 = (c[2] - oo[2]) * iz, tz1 = (c[5] - oo[2]) * iz;
+    const double t_in = std::fmax(std::fmax(std::fmin(tx0, tx1), std::fmin(ty0, ty1)), std::fmax(std::fmin(tz0, tz1), 0.0));
+    const double t_out = std::fmin(std::fmin(std::fmax(tx0, tx1), std::fmax(ty0, ty1)), std::fmax(tz0, tz1));
+    need[i] = (t_in <= t_out) ? 1 : 0;
   }
   return TOR_OK;
 }

@@ -126,6 +126,42 @@ TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v ocx, f2v ocy
   return m;
 }
 
+// ---- float32 slab test for the culling boxes (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) ---------------------------------
+// Box records hold {lo, hi} per axis relative to P, lo rounded down and hi rounded up from the float64 box (which is
+// itself inflated by 1e-6 relative around the swept spheres).  The ray side: o^ = fl(o - P) is off by <= u |o-P|, and
+// fl((lo, hi) - o^) adds <= u (|lo| + |o^|): both are absorbed by testing the box inflated by e = 3 u (|o-P| + max|box|)
+// on every side, folded into the per-lane addend (-o^ - e, -o^ + e).  What remains is relative: the entry / exit
+// parameters carry <= 2.5 u (rounding of d, of 1/d and of the product), so `t_in <= t_out (1 + 2^-20)` keeps every box
+// whose exact test passes.  NaN (0 * inf on an axis the ray is parallel to, or a NaN padding box) is dropped by
+// min/max exactly as in the float64 test.
+struct BoxRay32 {
+  f2v ax, ay, az;  // (-o^ - e, -o^ + e) per axis
+  f2v ix, iy, iz;  // 1/d^ per axis, both halves
+};
+
+TOR_HD BoxRay32 make_box_ray32(const RayF32& r, float bmax) {
+  BoxRay32 b;
+  const float e = 3.0f * kU32 * (r.ro + bmax);
+  b.ax = (f2v){-r.ox - e, -r.ox + e};
+  b.ay = (f2v){-r.oy - e, -r.oy + e};
+  b.az = (f2v){-r.oz - e, -r.oz + e};
+  b.ix = splat2(1.0f / r.dx);
+  b.iy = splat2(1.0f / r.dy);
+  b.iz = splat2(1.0f / r.dz);
+  return b;
+}
+
+// 1: the ray may touch the box {bx = (lo.x, hi.x), by, bz}; 0: it cannot.
+TOR_HD unsigned slab_bit32(const BoxRay32& b, f2v bx, f2v by, f2v bz) {
+  const f2v tx = (bx + b.ax) * b.ix, ty = (by + b.ay) * b.iy, tz = (bz + b.az) * b.iz;
+  const float tx0 = tx.x, tx1 = tx.y, ty0 = ty.x, ty1 = ty.y, tz0 = tz.x, tz1 = tz.y;
+  const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)),
+                                     __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
+  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)),
+                                      __builtin_fmaxf(tz0, tz1));
+  return (t_in <= __builtin_fmaf(t_out, 0x1p-20f, t_out)) ? 1u : 0u;
+}
+
 // Host-side per-object constant k (rounded up) and eligibility; used by tor_scene.cpp and the self test.
 inline bool f32_eligible(double mc0, double dcn, double r2) {
   return std::isfinite(mc0) && std::isfinite(dcn) && std::isfinite(r2) && mc0 <= (double)kF32Lim * 0.5 &&

@@ -165,9 +165,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   // (a launch stages either the float64 compact records or the float32 pair records)
   float* stage32 = reinterpret_cast<float*>(stage);
   const lfptr shot32_lds = (lfptr)stage32;
+  float* stage_b32 = stage32 + p.shot32_lds_floats;  // float32 block boxes of two-level scenes
+  const lfptr bnd32_lds = (lfptr)stage_b32;
   if (staged) {
     if (F32) {
       for (int k = threadIdx.x; k < p.shot32_lds_floats; k += kThreads) stage32[k] = p.shot32[k];
+      for (int k = threadIdx.x; k < p.bnd32_lds_floats; k += kThreads) stage_b32[k] = p.bnd32[k];
     } else {
       for (int k = threadIdx.x; k < p.shot_lds_doubles; k += kThreads) stage[k] = p.shot[k];
     }
@@ -338,6 +341,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       RayF32 r32{};
       if (F32) r32 = make_ray_f32(ox, oy, oz, dx, dy, dz, a_strict, p.org[0], p.org[1], p.org[2]);
 
+      BoxRay32 b32{};
+      const bool boxes32 = F32 && BLOCKS && p.bnd32 != nullptr;
+      if (boxes32) b32 = make_box_ray32(r32, p.sp_bmax);
+
       int seg = 0;
       int i = 0;
       for (;;) {
@@ -424,6 +431,21 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
               }
+            }
+          } else if (F32 && BLOCKS && (seg_kind == 3 || seg_kind == 4)) {
+            // the same boxes through the float32 slab test (tor_filter32.hpp): 8 floats per record via scalar loads
+            cfptr rec = (cfptr)(uintptr_t)p.bnd32 + 8 * (long)(seg_begin + i);
+            for (; i < seg_count; i += kBlock) {
+              unsigned m = 0;
+#pragma unroll
+              for (int j = 0; j < kBlock; ++j)
+                m = (m << 1) | slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
+                                          (f2v){rec[8 * j + 4], rec[8 * j + 5]});
+              rec += 8 * kBlock;
+              m |= r32.wild;
+              q[qn * 64] = ((seg_kind == 3) ? 0x80000000u : 0x40000000u) | ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+              qn += (m != 0) ? 1u : 0u;
+              if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
             }
           } else if (BLOCKS && (seg_kind == 3 || seg_kind == 4)) {
             // TOR_ACCEL_BLOCKS: the records are inflated axis-aligned boxes around spatial blocks of 8
@@ -682,9 +704,20 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 expand_block(rec);
               } else {
                 // super box `rec`: slab-test its 8 block boxes, descend into the ones the ray can touch
+                unsigned mc = 0;
+                if constexpr (F32 != 0) {
+                  auto child32 = [&](auto cb) {
+#pragma unroll 4
+                    for (int j = 0; j < kBlock; ++j)
+                      mc = (mc << 1) | slab_bit32(b32, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
+                                                  (f2v){cb[8 * j + 4], cb[8 * j + 5]});
+                  };
+                  if (p.bnd32_lds_floats > 0) child32(bnd32_lds + (size_t)rec * (8 * kBlock));
+                  else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
+                  mc |= r32.wild;
+                } else {
                 const gdptr cb = (gdptr)(uintptr_t)p.bnd + (size_t)rec * (8 * kBlock);
                 const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
-                unsigned mc = 0;
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j) {
                   const double tx0 = (cb[8 * j + 0] - ox) * ix, tx1 = (cb[8 * j + 3] - ox) * ix;
@@ -695,6 +728,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   const double t_out = __builtin_fmin(__builtin_fmin(__builtin_fmax(tx0, tx1), __builtin_fmax(ty0, ty1)),
                                                       __builtin_fmax(tz0, tz1));
                   mc = (mc << 1) | ((t_in <= t_out) ? 1u : 0u);
+                }
                 }
                 while (mc != 0) {
                   const int cbit = 31 - __builtin_clz(mc);
@@ -1000,7 +1034,8 @@ static int clamp_w(int waves_per_simd) {
 static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? 1 : 0; }
 static size_t dynamic_lds(const KParams& p) {
-  return (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4;
+  return (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
+         (size_t)p.bnd32_lds_floats * 4;
 }
 
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {

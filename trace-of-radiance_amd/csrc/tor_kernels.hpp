@@ -48,6 +48,9 @@ struct KParams {
   int shot32_stride;      // 10 | 12 | 16 floats per pair
   int shot32_lds_floats;  // > 0: copy that many floats of shot32 into LDS per workgroup
   float sp_mc0max, sp_dcmax;
+  const float* bnd32;     // float32 boxes (8 floats per record, same indices as bnd): {lo.x hi.x lo.y hi.y lo.z hi.z 0 0} - org
+  float sp_bmax;          // max |box coordinate - org|
+  int bnd32_lds_floats;   // > 0: the block boxes (two-level scenes: the per-lane descent reads them) are staged in LDS too
   double sp_t0, sp_dt;    // the spatial movers' time group
   int spatial_base;    // first cold slot of the spatial blocks: block b owns cold[spatial_base + 8b .. +8)
   int n_segs;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -380,7 +381,9 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   // the super boxes (kind 4: first record n_bnd_p + 1 of the bounds array) and the lanes descend
   const size_t n_super = n_bnd_p / kPad;
   const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;
-  out.two_level = out.n_blocks > 96;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
+  size_t two_level_min = 96;
+  if (const char* e = std::getenv("TOR_TWO_LEVEL_MIN")) two_level_min = (size_t)std::atoll(e);
+  out.two_level = out.n_blocks > two_level_min;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
   if (out.two_level)
     out.always.segs.insert(out.always.segs.end(), {4.0, (double)(n_bnd_p + 1), (double)n_super_p, 0.0, 0.0, 0.0, 0.0, 0.0});
   else
@@ -503,6 +506,30 @@ bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::v
     for (int a = 0; a < 3; ++a) { bnd[8 * (super0 + sidx) + a] = lo[a]; bnd[8 * (super0 + sidx) + 3 + a] = hi[a]; }
   }
   return true;
+}
+
+float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], std::vector<float>& bnd32) {
+  const size_t n = bnd.size() / 8;
+  bnd32.assign(8 * n, 0.0f);
+  double bmax = 0.0;
+  for (size_t b = 0; b < n; ++b) {
+    const double* c = &bnd[8 * b];
+    float* r = &bnd32[8 * b];
+    if (c[0] != c[0]) {  // NaN box (padding): never entered
+      for (int k = 0; k < 6; ++k) r[k] = std::nanf("");
+      continue;
+    }
+    for (int ax = 0; ax < 3; ++ax) {
+      const double lo = c[ax] - origin[ax], hi = c[3 + ax] - origin[ax];
+      float flo = (float)lo, fhi = (float)hi;
+      if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+      if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+      r[2 * ax] = flo;
+      r[2 * ax + 1] = fhi;
+      bmax = std::max(bmax, std::max(std::fabs((double)flo), std::fabs((double)fhi)));
+    }
+  }
+  return f32_round_up(bmax);
 }
 
 }  // namespace tor

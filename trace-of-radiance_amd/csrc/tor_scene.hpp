@@ -69,4 +69,9 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
 // Returns false when the time range is not finite (caller falls back to brute force).
 bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::vector<double>& bnd);
 
+// The same boxes for the float32 slab test (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32): one record of 8 float32 per box,
+// same record indices as `bnd`, {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, 0, 0} relative to `origin`, lo rounded down
+// and hi rounded up (NaN records stay NaN).  Returns max |coordinate| over the valid boxes, rounded up.
+float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], std::vector<float>& bnd32);
+
 }  // namespace tor
