@@ -28,11 +28,16 @@
 // bound into the linear form above; |OC|^2 = C + r^2.)  The constants below carry a further 5-8 % of slack,
 // which also covers the roundings of the margin arithmetic itself and the 2^-50-relative gap between the
 // float64-computed D, HB, C and their real values.  For |o-P|, |c-P| ~ 15 and r = 0.2 (random_scene) the
-// margins widen a sphere by < 1 % -- the filter keeps ~2 % more candidates than the exact sign test.
+// margins widen a sphere by < 1 %: ~2 % more candidates for rays that come from elsewhere, plus the sphere a
+// scattered ray starts on (its c ~ 0: the float64 sign test resolves it, float32 cannot) -- measured 1.43
+// candidates per query instead of 1.25.
 //
-// tests/test_filter32.py drives filter_one() (host build of this header) with random and adversarial
-// (tangent, origin on the surface, far-away, tiny direction) ray/sphere pairs and checks it never drops an
-// object the float64 test keeps; the GPU parity tests then compare whole canvases bit for bit.
+// The second half of the file is the float32 slab test for the culling boxes of TOR_ACCEL_BLOCKS (slab_bit32).
+//
+// tests/test_filter32.py drives filter_one() / slab_bit32 (host build of this header) with random and
+// adversarial (tangent, origin on the surface, far-away, tiny direction; box corners, edges, faces, axis-parallel
+// rays) pairs and the scene layouts, and checks they never drop what the float64 test keeps; the GPU parity tests
+// and tools/fuzz_accel.py then compare whole canvases bit for bit.
 #pragma once
 
 #include "tor_math.hpp"
