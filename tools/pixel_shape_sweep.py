@@ -1,5 +1,5 @@
 import importlib, os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tor = importlib.import_module("trace-of-radiance_amd")
 H, W, SPP = 1080, 1920, int(os.environ.get("SPP", "100"))
 scene, cam = tor.random_scene(0xFACADE), tor.camera()

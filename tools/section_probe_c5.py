@@ -1,5 +1,5 @@
 import importlib, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 tor = importlib.import_module("trace-of-radiance_amd")
 H, W, SPP = 1080, 1920, 64
