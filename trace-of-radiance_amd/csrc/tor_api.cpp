@@ -419,7 +419,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       p.sp_mc0max = hacc.sp_mc0max; p.sp_dcmax = hacc.sp_dcmax;
       p.sp_t0 = hacc.sp_t0; p.sp_dt = hacc.sp_dt;
     }
-    // LDS staging of the block records next to the per-wave queues (18 KB per workgroup, 160 KB per CU): the
+    // LDS staging of the block records next to the per-wave queues (10 KB per workgroup in these variants, 160 KB per CU): the
     // float32 pair records (TOR_ACCEL_F32; survivors are re-tested from the cold records -- staging the float64
     // records as well measured +2 % at best) or the float64 compact records.  It must fit at this mode's
     // workgroups/CU, else one workgroup fewer, else global loads.
@@ -436,7 +436,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     int& wg = stage_wg;
     wg = 0;
     auto fits = [&](size_t bytes, int wgs) {
-      return bytes <= hard_cap && bytes + 18432 <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
+      return bytes <= hard_cap && bytes + (size_t)tor::integrate_fixed_lds_bytes(1) <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
     };
     for (int tryw = ctx->max_blocks_per_cu[o.seeding][o.accel != 0]; tryw >= 2 && wg == 0; --tryw)
       if (fits(hot_bytes, tryw)) wg = tryw;

@@ -101,16 +101,21 @@ __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, doub
 #endif
 }
 
-constexpr int kQCap = 16;   // candidate-queue entries per lane (LDS, u32): (block << 8) | 8-bit mask
+// candidate-queue entries per lane (LDS, u32): (block << 8) | 8-bit mask.  Brute-force scenes queue one entry per
+// 8 objects with a candidate; with TOR_ACCEL_BLOCKS the entries are box masks (8 blocks each) and a lane rarely
+// holds more than a handful, so those variants run with half the queue -- the 8 KB per workgroup are what lets
+// the block boxes of a 1600-object scene sit in LDS next to its records.  A full queue is not an error: the loop
+// resolves what is queued and resumes.
+constexpr int queue_cap(int blocks) { return blocks ? 8 : 16; }
 constexpr int kBlock = 8;   // objects per queue entry; hot arrays are padded to this (= kPad)
 constexpr int kTilePixels = 64;  // SEED_PIXEL work unit: one wave-load of consecutive pixels
 constexpr int kAccSlots = 16;  // per-wave LDS pixel-accumulator cache (TOR_SEED_SAMPLE)
 static_assert(kBlock == kPad, "hot-record padding must equal the candidate block size");
 
-// LDS per wave: queue (kQCap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
+// LDS per wave: queue (queue_cap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
 constexpr int kProfSlots = 8;   // debug counters of the wave log (u64): 5 section sums, trips, spare, last time stamp
-constexpr int kWaveLdsBytes = kQCap * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8;
-static_assert(kWaveLdsBytes % 16 == 0, "keep LDS carve-outs 16-byte aligned");
+constexpr int wave_lds_bytes(int blocks) { return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8; }
+static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0, "keep LDS carve-outs 16-byte aligned");
 
 // The camera (24 float64) is needed once per new path only; read it there instead of keeping
 // it in 48 SGPRs across the object loop.  The empty asm makes the pointer opaque per call so
@@ -143,6 +148,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  constexpr int kQCap = queue_cap(BLOCKS);
+  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS);
   unsigned char* wave_lds = smem_raw + wave * kWaveLdsBytes;
   unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
   double* acc_lds = reinterpret_cast<double*>(wave_lds + kQCap * 64 * 4);          // [kAccSlots][3]
@@ -1034,7 +1041,7 @@ static int clamp_w(int waves_per_simd) {
 static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? 1 : 0; }
 static size_t dynamic_lds(const KParams& p) {
-  return (size_t)kWaveLdsBytes * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
+  return (size_t)wave_lds_bytes(wants_blocks(p)) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
          (size_t)p.bnd32_lds_floats * 4;
 }
 
@@ -1064,6 +1071,8 @@ int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_
   if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, dynamic_lds(p)) != hipSuccess || n < 1) n = 1;
   return n;
 }
+
+int integrate_fixed_lds_bytes(int blocks) { return wave_lds_bytes(blocks) * (kThreads / 64); }
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {
   if (n_values <= 0) return hipSuccess;

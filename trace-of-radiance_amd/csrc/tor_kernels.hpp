@@ -72,6 +72,7 @@ struct KParams {
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream);
 int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_per_simd);
+int integrate_fixed_lds_bytes(int blocks);  // per workgroup: queues, accumulator cache, debug counters
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
 hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream);
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
