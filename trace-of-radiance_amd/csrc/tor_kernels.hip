@@ -113,7 +113,7 @@ constexpr int kAccSlots = 16;  // per-wave LDS pixel-accumulator cache (TOR_SEED
 static_assert(kBlock == kPad, "hot-record padding must equal the candidate block size");
 
 // LDS per wave: queue (queue_cap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
-constexpr int kProfSlots = 8;   // debug counters of the wave log (u64): 5 section sums, trips, spare, last time stamp
+constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 5 section sums, trips, begin, last stamp, 4 statistics, 3 wave-log stamps
 constexpr int wave_lds_bytes(int blocks) { return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8; }
 static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0, "keep LDS carve-outs 16-byte aligned");
 
@@ -209,16 +209,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned cur_pl = 0, cur_s = 0;
   unsigned next_chunk = p.chunk;
   bool exhausted = false;
-  unsigned long long st_queries = 0, st_cand = 0, st_iters = 0, st_samples = 0;
-  const unsigned long long t_start = (p.wave_log != nullptr) ? wall_clock64() : 0ull;
-  unsigned long long t_exh = 0, it_exh = 0;
+  // statistics (tor_last_stats / wave log) live in LDS and are touched only when they were asked for: the
+  // kernel is short of scalar registers, counters that are always live would be paid for on every launch
+  const bool stats_on = p.stats != nullptr;
   // debug (wave_log only): shader-clock cycles per section of the bounce iteration and trips of the resolve
   // loop, kept in LDS (lane 0) so that the counters cost no registers when they are off
   const bool prof = p.wave_log != nullptr;
-  enum { kSecRefill = 0, kSecLoop, kSecResolve, kSecShade, kSecDeposit, kSecTrips, kSecBegin, kSecMark };
-  if (prof && lane == 0) {
+  enum { kSecRefill = 0, kSecLoop, kSecResolve, kSecShade, kSecDeposit, kSecTrips, kSecBegin, kSecMark,
+         kStQueries, kStCand, kStIters, kStSamples, kLogStart, kLogExhausted, kLogItersAtExhaustion };
+  if ((stats_on || prof) && lane == 0) {
     for (int k = 0; k < kProfSlots; ++k) prof_lds[k] = 0;
     prof_lds[kSecBegin] = prof_lds[kSecMark] = __builtin_readcyclecounter();
+    if (prof) prof_lds[kLogStart] = wall_clock64();
   }
 #define TOR_SEC(slot)                                             \
   if (prof && lane == 0) {                                        \
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         base = bcast_first_u64(__shfl(base, leader));
         if (base >= p.total_work) {
           exhausted = true;
-          if (p.wave_log != nullptr) { t_exh = wall_clock64(); it_exh = st_iters; }
+          if (prof && lane == 0) { prof_lds[kLogExhausted] = wall_clock64(); prof_lds[kLogItersAtExhaustion] = prof_lds[kStIters]; }
         } else {
           w_next = base;
           w_end = (base + grab < p.total_work) ? base + grab : p.total_work;
@@ -328,8 +330,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       if (exhausted) break;
       continue;
     }
-    st_iters += 1;
-    st_queries += (unsigned long long)__builtin_popcountll(active_mask);
+    if (stats_on && lane == 0) {
+      prof_lds[kStIters] += 1;
+      prof_lds[kStQueries] += (unsigned long long)__builtin_popcountll(active_mask);
+    }
     if (kProbe && active) path_q += 1;
     bool ended = false;
     V3 radiance = v3(0.0, 0.0, 0.0);
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               using T12 = std::integral_constant<int, 12>;
               using T16 = std::integral_constant<int, 16>;
               auto expand_block = [&](unsigned blk_id) {
-                st_cand += kBlock;
+                if (stats_on) atomicAdd(&prof_lds[kStCand], (unsigned long long)kBlock);
                 if constexpr (F32 != 0) {
                   // (the host pairs the float32 kernel variant with float32 block records, or with no blocks at all)
                   const size_t off = (size_t)blk_id * (size_t)(p.shot32_stride * (kBlock / 2));
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 }
               }
             } else {
-              st_cand += 1;
+              if (stats_on) atomicAdd(&prof_lds[kStCand], 1ull);
               exact_cold(rec);
             }
           }
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
       if (ended) {
         active = false;
-        st_samples += 1;
+        if (stats_on) atomicAdd(&prof_lds[kStSamples], 1ull);
         if (kProbe) {
           atomicAdd(p.tile_cost + ((unsigned)pix / kTilePixels), (unsigned)path_q);
           path_q = 0;
@@ -875,17 +879,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       if (tag >= 0) unsafeAtomicAdd(p.out + (size_t)tag * 3 + ch, acc_lds[slot * 3 + ch]);
     }
   }
-  if (p.stats != nullptr) {
-    unsigned long long cand = st_cand, smp = st_samples;
-    for (int off = 32; off > 0; off >>= 1) {
-      cand += __shfl_xor(cand, off);
-      smp += __shfl_xor(smp, off);
-    }
+  if (stats_on) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0 && p.wave_log != nullptr) {
       unsigned long long* w = p.wave_log + (size_t)(blockIdx.x * (kThreads / 64) + wave) * 8;
-      w[0] = t_start; w[1] = wall_clock64(); w[2] = st_iters;
-      w[3] = st_queries | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
-      w[4] = t_exh; w[5] = (it_exh & 0xffffffffull) | (prof_lds[kSecTrips] << 32);
+      w[0] = prof_lds[kLogStart]; w[1] = wall_clock64(); w[2] = prof_lds[kStIters];
+      w[3] = prof_lds[kStQueries] | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
+      w[4] = prof_lds[kLogExhausted]; w[5] = (prof_lds[kLogItersAtExhaustion] & 0xffffffffull) | (prof_lds[kSecTrips] << 32);
       // six 21-bit fields in units of 4096 shader cycles: refill+camera, object loop, exact resolve | shade, deposit, total
       const unsigned long long total = __builtin_readcyclecounter() - prof_lds[kSecBegin];
       auto f21 = [](unsigned long long c) { c >>= 12; return c > 0x1fffffull ? 0x1fffffull : c; };
@@ -893,10 +893,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       w[7] = f21(prof_lds[kSecShade]) | (f21(prof_lds[kSecDeposit]) << 21) | (f21(total) << 42);
     }
     if (lane == 0) {
-      atomicAdd(p.stats + 0, st_queries);
-      atomicAdd(p.stats + 1, cand);
-      atomicAdd(p.stats + 2, st_iters);
-      atomicAdd(p.stats + 3, smp);
+      atomicAdd(p.stats + 0, prof_lds[kStQueries]);
+      atomicAdd(p.stats + 1, prof_lds[kStCand]);
+      atomicAdd(p.stats + 2, prof_lds[kStIters]);
+      atomicAdd(p.stats + 3, prof_lds[kStSamples]);
     }
   }
 }
