@@ -206,6 +206,7 @@ def main():
         torch.cuda.set_device(0)
         dev_index = 0
     tor = importlib.import_module("trace-of-radiance_amd")
+    tor.ensure_built()   # a fresh checkout has no in-tree .so yet (file-locked: the ranks may race)
 
     H, W = args.height, args.width
     if args.workload == "c5":

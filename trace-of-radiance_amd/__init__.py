@@ -131,12 +131,27 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    """Compile libtor_mi355x.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile libtor_mi355x.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  Serialised by a
+    file lock: the ranks of a multi-GPU launch may all find the library missing at the same time."""
+    import fcntl
     src_dir = os.path.join(_HERE, "csrc")
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.run(["make", "-C", src_dir, "-B", "all"], check=True, capture_output=True)
-    else:
-        subprocess.run(["make", "-C", src_dir, "all"], check=True, capture_output=True)
+    with open(os.path.join(src_dir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not os.path.exists(LIB_PATH):
+                subprocess.run(["make", "-C", src_dir, "-B", "all"], check=True, capture_output=True)
+            else:
+                subprocess.run(["make", "-C", src_dir, "all"], check=True, capture_output=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB_PATH
+
+
+def ensure_built() -> str:
+    """Build the HIP extension if the in-tree library is missing (a fresh checkout); never a fallback --
+    without hipcc this raises."""
+    if not os.path.exists(LIB_PATH):
+        build()
     return LIB_PATH
 
 
