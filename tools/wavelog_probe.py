@@ -26,7 +26,7 @@ for mode in (tor.SEED_PIXEL, tor.SEED_SAMPLE):
     # time per iteration vs time
     rate = (end - start) * 1e3 / it
     print(f"   us/iteration per wave: p10 {np.percentile(rate,10):.1f} p50 {np.median(rate):.1f} p90 {np.percentile(rate,90):.1f}")
-    texh = (wl[:, 4] - t0) / 100e3; itx = wl[:, 5]
+    texh = (wl[:, 4] - t0) / 100e3; itx = (raw[:, 5] & np.uint64(0xffffffff)).astype(np.float64)   # word 5 = iterations at exhaustion | resolve-loop trips << 32
     print(f'   counter dry seen at: min {texh.min():.1f} p50 {np.median(texh):.1f} max {texh.max():.1f} ms; iterations after dry: p50 {np.median(it - itx):.0f} p90 {np.percentile(it - itx, 90):.0f} max {(it - itx).max():.0f}; tail duration p50 {np.median(end - texh):.1f} p90 {np.percentile(end - texh, 90):.1f} max {(end - texh).max():.1f} ms')
     hist, edges = np.histogram(end, bins=12)
     print("   end-time histogram:", list(zip(np.round(edges[:-1]).astype(int), hist)))
