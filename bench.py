@@ -4,17 +4,24 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one frame of the benchmark workload: BASELINE.json
-configs[1], the reference's random_scene (seed 0xFACADE, 485 objects) at 1920x1080, 100 spp,
-depth 50, rendered with the counter-based per-sample streams (TOR_SEED_SAMPLE) and the
-reference's rounding (TOR_ARITH_STRICT).  Scene and camera are resident in HBM before the timed
-region; the frame stays on the device.
+Workload (default): BASELINE.json configs[2] -- the configuration the target is quoted on -- the
+reference's random_scene (seed 0xFACADE, 485 objects) at 1920x1080, 1000 spp, depth 50, rendered with the
+counter-based per-sample streams (TOR_SEED_SAMPLE) and the reference's rounding and algorithm
+(TOR_ARITH_STRICT, float64 brute-force closest hit).  A step = one pass of the hot path over one frame.
 
-N > 1 (one process per GPU, RCCL): image rows are dealt to the ranks round-robin (render.nim:55's
-`parallelFor row` across GPUs), every rank renders its rows, then ONE all_gather of the
-row shards (the framebuffer gather over xGMI) -- both inside the timed region.  Weak scaling:
-samples per pixel grow with N (100*N), so every GPU traces the same number of samples as the
-single-GPU run.
+Two timed regions are reported on one GPU, each over the same K steps:
+  value         -- the harness contract's region: scene and camera resident in HBM before the clock starts, the
+                   frame stays on the device (tor_render_device).
+  host_canvas   -- SURVEY 8(d)'s region, what a Nim caller of render() pays
+                   (trace_of_radiance.nim:60-64): tor_render_opt on a HOST canvas = scene + camera H2D (the
+                   scene is cached after the first call), kernels, D2H into canvas.pixels.
+N > 1 (one process per GPU): image rows are dealt to the ranks round-robin (render.nim:55's `parallelFor row`
+across GPUs), every rank renders its rows, then ONE gather of the row shards to rank 0 over xGMI --
+tor_render_gather_device: RCCL inside the library (falls back to torch.distributed's all_gather, also RCCL,
+if the library's communicator cannot be set up) -- both inside the timed region.  Weak scaling: samples per
+pixel grow with N (spp*N), so every GPU traces the same number of samples as the single-GPU run.
+`python bench.py --gpus N` WITHOUT torchrun drives N devices from one process through the drop-in itself
+(TorOptions.devices): the path a Nim host uses.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
@@ -22,21 +29,26 @@ import argparse
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Algorithmic work per pixel-sample on the benchmark scene (BASELINE.md 4,
-# re-measured by the oracle's counters: tests/golden/kat.json): 2.60 closest-hit queries x 485
-# objects = 1262 ray/object tests x 32.8 float64 ops (reference formulation, nothing hoisted,
-# nothing fused) + ~0.5 k for camera/scatter/sky.
-FLOPS_PER_SAMPLE = 41.9e3
+# Algorithmic work per pixel-sample on the benchmark scene: every closest-hit
+# query tests all 485 objects; per test the reference's formulation costs 23 (static sphere, 90 objects) or
+# 35 (moving sphere, 395 objects) float64 operations -- nothing hoisted, nothing fused -- + ~0.5 k per sample
+# for camera/scatter/sky.  Queries per sample are MEASURED in the run (tor_last_stats), 2.60 at 1080p.
+OPS_PER_TEST_STATIC, OPS_PER_TEST_MOVING, OPS_PER_SAMPLE_FIXED = 23.0, 35.0, 500.0
+FLOPS_PER_SAMPLE_SURVEY = 41.9e3
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2.4 GHz  (datasheet)
 PEAK_FP64_NOFMA_TFLOPS = 39.3    # the same issue rate with add/mul only (the reference has no FMA)
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+ACCEL_BITS = {"none": 0, "blocks": 1, "f32": 2, "blocks+f32": 3}
 
 
 def parse_args():
@@ -46,55 +58,148 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=100, help="samples per pixel per GPU (x N ranks)")
+    ap.add_argument("--spp", type=int, default=1000, help="samples per pixel per GPU (x N ranks)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seeding", choices=["sample", "pixel"], default="sample")
     ap.add_argument("--arith", choices=["strict", "fused"], default="strict")
-    ap.add_argument("--accel", choices=["none", "blocks", "f32", "blocks+f32"], default="none",
-                    help="none: the reference's brute-force closest hit (the metric's algorithm); blocks: exact block culling (SURVEY 8 f4)")
+    ap.add_argument("--accel", choices=list(ACCEL_BITS), default="none",
+                    help="none: the reference's brute-force closest hit (the metric's algorithm); others: exact accelerations")
     ap.add_argument("--row-tile", type=int, default=1,
                     help="rows per shard tile; 1 = row-cyclic: every rank gets nrows/N rows (+-1) of statistically equal cost")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
-                    help="c2: random_scene frame (default, the metric's config); c5: BASELINE configs[4], the animated "
+    ap.add_argument("--workload", choices=["frame", "c5"], default="frame",
+                    help="frame: random_scene frame (default, the metric's config); c5: BASELINE configs[4], the animated "
                          "bouncing-spheres scene, 256 spp per frame, frames dealt round-robin to the GPUs (no collective)")
-    ap.add_argument("--verify", action="store_true", help="N > 1: also render the whole frame on every rank and require the gathered frame to be identical")
-    ap.add_argument("--no-accel-leg", action="store_true", help="skip the secondary TOR_ACCEL_BLOCKS measurement")
-    ap.add_argument("--stats", action="store_true", help="also collect the kernel's workload counters (untimed extra step)")
+    ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 also renders the whole frame alone and requires the gathered frame to be identical")
+    ap.add_argument("--no-accel-leg", action="store_true", help="skip the secondary exact-acceleration measurements")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-canvas (SURVEY 8d) region")
+    ap.add_argument("--no-stats", action="store_true", help="skip the untimed extra launch that collects the kernel's workload counters")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (HBM traffic of one launch)")
+    ap.add_argument("--aux-steps", type=int, default=3, help="steps of each secondary leg (host canvas, accelerations)")
+    ap.add_argument("--gather", choices=["lib", "torch"], default="lib", help="N > 1: framebuffer gather inside the library (RCCL) or torch.distributed")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def measured_profile(W, H, spp, seeding, arith, accel="none"):
-    """What the committed rocprofv3 PMC passes (profiles/traffic.json, rebuilt from the summaries by
-    tools/update_traffic.py) measured for this configuration: HBM bytes per launch of the dominant kernel and
-    its executed-instruction counters; {} otherwise."""
+def config_name(W, H, spp_per_gpu, world):
+    """Which BASELINE.json configs[] entry this run is (derived from the sizes, never hard-coded)."""
+    if (W, H) == (1920, 1080) and spp_per_gpu == 100 and world == 1:
+        return "BASELINE configs[1]"
+    if (W, H) == (1920, 1080) and spp_per_gpu == 1000:
+        return "BASELINE configs[2]" + ("" if world == 1 else f" weak-scaled to {world} GPUs")
+    if (W, H) == (3840, 2160) and spp_per_gpu * world == 4096:
+        return "BASELINE configs[3]"
+    if (W, H) == (384, 216) and spp_per_gpu == 100 and world == 1:
+        return "BASELINE configs[0] geometry on the GPU"
+    return "custom size (not a BASELINE config)"
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def from_profile(W, H, spp, seeding, arith, accel="none"):
+    """What the COMMITTED rocprofv3 PMC passes (profiles/traffic.json, rebuilt from the summaries by
+    tools/update_traffic.py) measured for this configuration on an earlier run -- evidence, not a measurement of
+    this run; {} when there is none."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        return t[f"{W}x{H}x{spp}:{seeding}:{arith}" + ("" if accel == "none" else ":" + accel)]
+        e = dict(t[f"{W}x{H}x{spp}:{seeding}:{arith}" + ("" if accel == "none" else ":" + accel)])
+        e["_what"] = "replayed from committed rocprofv3 summaries (profiles/), NOT measured in this run"
+        e["_profiles_commit"] = git_head()
+        return e
     except Exception:
         return {}
 
 
-def measured_traffic(W, H, spp, seeding, arith, accel="none"):
-    return measured_profile(W, H, spp, seeding, arith, accel).get("bytes")
+# ---------------------------------------------------------------------------------------------------------
+# live HBM traffic: rocprofv3 --pmc around ONE launch of the same kernel/config, in a child process
+# ---------------------------------------------------------------------------------------------------------
+def pmc_child(spec):
+    """Child of live_traffic(): one launch through the bare C ABI (ctypes only, no torch)."""
+    W, H, spp, depth, seeding, arith, accel = (int(x) for x in spec.split(","))
+    os.environ["TOR_NO_TORCH"] = "1"
+    tor = importlib.import_module("trace-of-radiance_amd")
+    scene, cam = tor.random_scene(0xFACADE), tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
+    cv = tor.new_canvas(H, W, spp, 2.2)
+    tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, arith=arith, accel=accel))
+    print("pmc-child done", float(cv.pixels.mean()))
 
 
+def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=150):
+    """HBM bytes of ONE integrate_kernel launch of this configuration, from two separate rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots'), corrected as the
+    guide's HBM section says: FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE is
+    taken as is (uncalibrated); both are reported in KiB by rocprofv3.  None when rocprofv3 is missing or fails."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    import glob
+    import sqlite3
+    out = {}
+    base = tempfile.mkdtemp(prefix="tor_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", TOR_NO_TORCH="1")
+    spec = f"{W},{H},{spp},{depth},{seeding},{arith},{accel}"
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                                "--pmc-child", spec], capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed: {r.stderr[-300:]}"
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None, f"rocprofv3 --pmc {counter}: no rocpd database"
+            con = sqlite3.connect(dbs[0])
+            rows = con.execute("select name, sum(counter_value), max(duration) from pmc_events where counter_name = ? "
+                               "group by name, dispatch_id", (counter,)).fetchall()
+            rows = [r_ for r_ in rows if "integrate_kernel" in r_[0]]
+            if not rows:
+                return None, f"rocprofv3 --pmc {counter}: no integrate_kernel dispatch in the database"
+            best = max(rows, key=lambda r_: r_[2])          # the frame's launch (the 2-spp cost probe is tiny)
+            out[counter] = float(best[1])
+            out[counter + "_kernel_ms"] = float(best[2]) / 1e6
+    except Exception as e:  # noqa
+        return None, f"live PMC pass failed: {e!r}"
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    out["bytes"] = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+    return out, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = checker; imported only here)
+# ---------------------------------------------------------------------------------------------------------
 def cpu_baseline(width, height, spp, depth, target_seconds):
-    """The oracle in its reference-faithful mode (per-pixel streams, libm, no FMA), OpenMP over
-    rows with schedule(dynamic,1) -- the analogue of Weave's parallelFor row (render.nim:55) --
-    on all host cores, over every k-th row of the SAME frame so that it takes ~target_seconds."""
+    """The oracle in its reference-faithful mode (per-pixel streams, libm, no FMA), OpenMP over rows with
+    schedule(dynamic,1) -- the analogue of Weave's parallelFor row (render.nim:55) -- on all host cores.
+    (1) BASELINE configs[0] in full (384x216x100, the reference's own main()): timed, and its PPM quantisation
+        is compared with the reference's golden PNG IN THIS RUN (BASELINE.md 3);
+    (2) every k-th row of the bench frame, sized for ~target_seconds: the `value`."""
     from oracle import oracle as O
+    import numpy as np
     objs, _ = O.random_scene(0xFACADE)
     cam = O.camera()
     cores = O.num_threads()
-    # calibrate on ~one row per core, then size the strided sample for ~target_seconds
-    step_cal = max(1, height // max(min(height, cores), 1))
-    rows_cal = len(range(0, height, step_cal))
     t = time.perf_counter()
-    O.render(height, width, spp, cam, objs, max_depth=depth, row_step=step_cal)
-    rate = rows_cal * width * spp / max(time.perf_counter() - t, 1e-6)  # samples/s, rough
+    c1 = O.render(216, 384, 100, cam, objs, max_depth=50)
+    c1_dt = time.perf_counter() - t
+    png_equal, png_note = None, None
+    try:
+        from PIL import Image
+        g = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "book2_motion_blur.png")).convert("RGB"))
+        rgb = O.quantize_ppm(c1.pixels)
+        png_equal = bool(np.array_equal(rgb, g))
+        png_note = f"{int((rgb != g).sum())} of {g.size} 8-bit channels differ"
+    except Exception as e:  # noqa
+        png_note = f"not checked: {e!r}"
+    rate = 216 * 384 * 100 / max(c1_dt, 1e-6)
     want_rows = int(min(height, max(cores, rate * target_seconds / (width * spp))))
     step = max(1, height // max(want_rows, 1))
     rows = len(range(0, height, step))
@@ -115,9 +220,11 @@ def cpu_baseline(width, height, spp, depth, target_seconds):
         "value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"every {step}th row ({rows} of {height} rows) of the {width}x{height}x{spp}spp frame, "
                   f"depth {depth}: {samples / 1e6:.1f} Msamples in {dt:.1f} s; oracle/tor_oracle.c faithful mode "
-                  f"(seed(row,col) streams, libm, -ffp-contract=off; bit-identical to the reference's golden PNG), "
-                  f"OpenMP schedule(dynamic,1) over rows",
+                  f"(seed(row,col) streams, libm, -ffp-contract=off), OpenMP schedule(dynamic,1) over rows",
         "cpu_model": model,
+        "c1": {"workload": "BASELINE configs[0]: 384x216, 100 spp, depth 50 (trace_of_radiance.nim main())",
+               "value": round(216 * 384 * 100 / c1_dt / 1e6, 4), "seconds": round(c1_dt, 3),
+               "ppm_equals_reference_png": png_equal, "ppm_vs_png": png_note},
     }
 
 
@@ -125,7 +232,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
     """BASELINE configs[4]: scenes_animated bouncing spheres, frame-parallel (frame f -> GPU f mod N,
     SURVEY 8e): a step = one frame per GPU: scene upload (1601 objects) + integrator.  No collective."""
     H, W = args.height, args.width
-    spp = args.spp if args.spp != 100 else 256
+    spp = args.spp if args.spp != 1000 else 256
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
     arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
     n_steps = args.warmup + args.steps
@@ -140,10 +247,13 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
     opt = tor.make_options(seeding=seeding, arith=arith, accel=ACCEL_BITS[args.accel])
     buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    upload_s = [0.0]
 
     def step(i):
         cam, scene = frames[i]
+        t = time.perf_counter()
         ctx.upload(scene.list())
+        upload_s[0] += time.perf_counter() - t
         ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt, buf.data_ptr(), stream)
 
     for i in range(args.warmup):
@@ -151,6 +261,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    upload_s[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         step(i)
@@ -172,18 +283,62 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
             "vs_baseline": None, "dtype": "f64" if args.accel == "none" else "f64 (canvas bit-identical to the float64 path)", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4]: scenes_animated (1601 static spheres per frame), {W}x{H}, {spp} spp, "
                                    f"depth {args.depth}, one frame per GPU per step", "seeding": args.seeding, "arith": args.arith,
-                       "parallelism": f"frame f -> GPU f mod {max(world, 1)}, no collective"},
-            "kernel_ms": round(k_ms, 3), "frames_per_s": round(args.steps * max(world, 1) / elapsed, 3)}), flush=True)
+                       "accel": args.accel, "parallelism": f"frame f -> GPU f mod {max(world, 1)}, no collective"},
+            "kernel_ms": round(k_ms, 3), "frames_per_s": round(args.steps * max(world, 1) / elapsed, 3),
+            "scene_upload_ms_per_frame": round(upload_s[0] / args.steps * 1e3, 3)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-ACCEL_BITS = {"none": 0, "blocks": 1, "f32": 2, "blocks+f32": 3}
+def bench_single_process_multi_device(args, tor):
+    """`python bench.py --gpus N` without torchrun: ONE process drives N devices through the drop-in itself
+    (tor_render_opt with TorOptions.devices: a host thread + stream per device, row-cyclic shards, framebuffer
+    gather) -- the path a Nim host takes.  Timed region = SURVEY 8(d): host canvas in, host canvas out."""
+    import torch
+    H, W, N = args.height, args.width, args.gpus
+    spp = args.spp * N
+    n_dev = max(torch.cuda.device_count(), 1)
+    devices = [k % n_dev for k in range(N)]
+    scene = tor.random_scene(0xFACADE)
+    cam = tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
+    seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
+    arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
+    opt = tor.make_options(seeding=seeding, arith=arith, accel=ACCEL_BITS[args.accel], row_tile=args.row_tile, devices=devices)
+    cv = tor.new_canvas(H, W, spp, 2.2)
+    for _ in range(args.warmup):
+        tor.render(cv, cam, scene.list(), args.depth, opt)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tor.render(cv, cam, scene.list(), args.depth, opt)
+    elapsed = time.perf_counter() - t0
+    timing = tor.last_render_timing()
+    verified = None
+    if args.verify:
+        one = tor.new_canvas(H, W, spp, 2.2)
+        tor.render(one, cam, scene.list(), args.depth, tor.make_options(seeding=seeding, arith=arith, accel=ACCEL_BITS[args.accel]))
+        import numpy as np
+        verified = bool(np.array_equal(one.pixels, cv.pixels))
+        if not verified:
+            raise SystemExit("multi-device canvas differs from the single-device canvas")
+    print(json.dumps({
+        "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(H * W * spp * args.steps / elapsed / 1e6, 2),
+        "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{config_name(W, H, args.spp, N)}: random_scene seed 0xFACADE (485 objects), {W}x{H}, {spp} spp "
+                               f"({args.spp} per GPU), depth {args.depth}", "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
+                   "parallelism": f"ONE process, tor_render_opt with devices={devices}: row tiles of {args.row_tile} dealt to {N} "
+                                  f"device contexts, framebuffer gather inside the library",
+                   "timed_region": "SURVEY 8(d): host canvas in/out (scene cached after the first call)"},
+        "last_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
+        "canvas_identical_to_single_device": verified, "roofline": None, "cpu_baseline": None}), flush=True)
 
 
 def main():
     args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args.pmc_child)
     import torch
     import torch.distributed as dist
 
@@ -211,28 +366,56 @@ def main():
     H, W = args.height, args.width
     if args.workload == "c5":
         return bench_animation(args, tor, torch, dist, world, rank, local_rank)
+    if world == 1 and n_gpus > 1:
+        return bench_single_process_multi_device(args, tor)
     spp = args.spp * max(world, 1)  # weak scaling: per-GPU samples fixed
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
     arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
+    accel = ACCEL_BITS[args.accel]
 
     scene = tor.random_scene(0xFACADE)
     cam = tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
     ctx = tor.Context(dev_index)
     ctx.upload(scene.list())
-    opt = tor.make_options(seeding=seeding, arith=arith, shard_index=rank if world > 1 else 0,
-                           shard_count=max(world, 1), row_tile=args.row_tile,
-                           accel=ACCEL_BITS[args.accel])
-    tdist = importlib.import_module("trace-of-radiance_amd.distributed")
-    plan = tdist.ShardPlan(H, args.row_tile, max(world, 1))
-    frame = tdist.DistributedFrame(plan, W, rank if world > 1 else 0, torch.device("cuda"))
-    my_rows = frame.my_rows
-    assert list(my_rows) == list(tor.shard_rows(H, args.row_tile, rank if world > 1 else 0, max(world, 1)))
+    shard = rank if world > 1 else 0
+    opt = tor.make_options(seeding=seeding, arith=arith, shard_index=shard, shard_count=max(world, 1), row_tile=args.row_tile,
+                           accel=accel)
+    my_rows = tor.shard_rows(H, args.row_tile, shard, max(world, 1))
     stream = torch.cuda.current_stream().cuda_stream
+    frame = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")   # world 1: the canvas; world > 1: rank 0's gathered frame
+
+    # ---- N > 1: the framebuffer gather.  Preferred: RCCL inside the library (tor_render_gather_device). ----
+    gather_kind = None
+    tframe = None
+    if world > 1:
+        gather_kind = "torch.distributed all_gather (RCCL)" if backend == "nccl" else f"torch.distributed all_gather ({backend})"
+        lib_ok = False
+        if args.gather == "lib" and backend == "nccl":
+            try:
+                uid = [tor.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init_rank(uid[0], rank, world)
+                lib_ok = True
+            except Exception as e:  # noqa
+                print(f"[bench rank {rank}] library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
+            flag = torch.tensor([1 if lib_ok else 0], dtype=torch.int64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            lib_ok = bool(flag.item())
+        if lib_ok:
+            gather_kind = "tor_render_gather_device: RCCL send/recv gather to rank 0 inside libtor_mi355x + de-interleave kernel"
+        else:
+            tdist = importlib.import_module("trace-of-radiance_amd.distributed")
+            tframe = tdist.DistributedFrame(tdist.ShardPlan(H, args.row_tile, world), W, rank, torch.device("cuda"))
+            assert list(tframe.my_rows) == list(my_rows)
 
     def step():
-        ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt, frame.shard.data_ptr(), stream)
-        if world > 1:
-            frame.gather()   # RCCL all_gather of the row shards over xGMI + rows put in place
+        if world == 1:
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt, frame.data_ptr(), stream)
+        elif tframe is None:
+            ctx.render_gather_device(cam, H, W, spp, 2.2, args.depth, opt, 0, frame.data_ptr(), stream)
+        else:
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt, tframe.shard.data_ptr(), stream)
+            tframe.gather()   # all_gather of the row shards over xGMI + rows put in place
 
     for _ in range(args.warmup):
         step()
@@ -252,42 +435,74 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # dominant kernel: integrate_kernel, per-launch HIP events on the launch stream
+    k_ms, k_n = ctx.kernel_ms_mean(args.steps)
 
+    verified = None
     if args.verify and world > 1:
         # the gathered frame must be the frame one process renders alone (any partition, any world size)
-        full = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
-        ctx.render_device(cam, H, W, spp, 2.2, args.depth,
-                          tor.make_options(seeding=seeding, arith=arith, accel=opt.accel), full.data_ptr(), stream)
-        torch.cuda.synchronize()
-        same = bool(torch.equal(full, frame.frame))
-        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device="cuda")
+        ok = 1
+        if rank == 0:
+            full = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, tor.make_options(seeding=seeding, arith=arith, accel=accel),
+                              full.data_ptr(), stream)
+            torch.cuda.synchronize()
+            ok = int(torch.equal(full, frame if tframe is None else tframe.frame))
+        flag = torch.tensor([ok], dtype=torch.int64, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verified = bool(flag.item())
         if not verified:
             raise SystemExit(f"rank {rank}: gathered frame differs from the single-process frame")
-    else:
-        verified = None
 
-    # dominant kernel: integrate_kernel, per-launch HIP events on the launch stream
-    k_ms, k_n = ctx.kernel_ms_mean(args.steps)
     local_samples = len(my_rows) * W * spp
     total_samples = H * W * spp
     value = total_samples * args.steps / elapsed / 1e6
 
     result = None
     if rank == 0:
+        # ---- workload counters of this very configuration, measured now (one extra, untimed launch) ----
+        live = None
+        flops_per_sample = FLOPS_PER_SAMPLE_SURVEY
+        if not args.no_stats:
+            ctx.set_stats(True)
+            one = torch.empty((len(my_rows), W, 3), dtype=torch.float64, device="cuda")
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt, one.data_ptr(), stream)
+            torch.cuda.synchronize()
+            st = ctx.last_stats()
+            ctx.set_stats(False)
+            n_obj = len(scene)
+            n_moving = sum(1 for i in range(n_obj) if scene.objects[i].kind == tor.MOVING_SPHERE)
+            q_per_sample = st.hit_queries / max(st.samples, 1)
+            ops_per_query = n_moving * OPS_PER_TEST_MOVING + (n_obj - n_moving) * OPS_PER_TEST_STATIC
+            flops_per_sample = q_per_sample * ops_per_query + OPS_PER_SAMPLE_FIXED
+            live = {
+                "what": "tor_last_stats of one extra launch of this configuration (counters in the kernel, untimed)",
+                "samples": int(st.samples), "hit_queries_per_sample": round(q_per_sample, 4),
+                "object_tests_per_sample": round(q_per_sample * n_obj, 1),
+                "candidates_per_query": round(st.candidates / max(st.hit_queries, 1), 3),
+                "lane_utilisation": round(st.hit_queries / max(st.lane_slots, 1), 4),
+                "algorithmic_fp64_ops_per_sample": round(flops_per_sample, 1),
+                "formula": f"queries/sample x ({n_moving} moving x 35 + {n_obj - n_moving} static x 23 float64 ops, the reference's "
+                           f"un-hoisted formulation, SURVEY 8d) + 500",
+            }
+            del one
         k_rate = local_samples / (k_ms * 1e-3)          # samples/s inside the kernel, this rank
-        tflops = k_rate * FLOPS_PER_SAMPLE / 1e12
-        hbm_bytes = len(my_rows) * W * 24.0 * 2 + 64e3  # canvas write (+ atomics read-modify-write) + scene
+        tflops = k_rate * flops_per_sample / 1e12
+        hbm_bytes = len(my_rows) * W * 24.0 * (2 if seeding == tor.SEED_SAMPLE else 1) + 64e3  # canvas write (+ clear in SAMPLE mode) + scene
+        traffic, traffic_note = None, "skipped (--no-pmc)" if args.no_pmc else None
+        if world == 1 and not args.no_pmc:
+            traffic, traffic_note = live_traffic(W, H, spp, args.depth, seeding, arith, accel)
         roof = {
             "bound": "valu_fp64", "kernel": "tor::integrate_kernel",
             "achieved": round(tflops, 3), "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / PEAK_FP64_VECTOR_TFLOPS, 4),
             "frac_of_nofma_peak": round(tflops / PEAK_FP64_NOFMA_TFLOPS, 4),
             "nofma_peak": PEAK_FP64_NOFMA_TFLOPS,
-            "flops_per_sample": FLOPS_PER_SAMPLE, "kernel_ms": round(k_ms, 3), "launches_averaged": k_n,
-            "traffic": measured_traffic(W, H, spp, args.seeding, args.arith, args.accel) if world == 1 else None,
-            "executed": measured_profile(W, H, spp, args.seeding, args.arith, args.accel).get("executed") if world == 1 else None,
+            "flops_per_sample": round(flops_per_sample, 1), "kernel_ms": round(k_ms, 3), "launches_averaged": k_n,
+            "traffic": traffic["bytes"] if traffic else None,
+            "traffic_detail": traffic if traffic else traffic_note,
+            "executed_live": live,
+            "from_profile": from_profile(W, H, spp, args.seeding, args.arith, args.accel) if world == 1 else None,
             "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 4), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 8),
                     "algorithmic_bytes_per_launch": hbm_bytes},
@@ -296,64 +511,90 @@ def main():
         }
         if args.accel != "none":
             # with an exact acceleration the rate is still quoted against the reference's brute-force
-            # float64 operation count, so frac can exceed 1; `executed` holds what the kernel really issued
+            # float64 operation count, so frac can exceed 1
             roof["note"] = ("--accel " + args.accel + ": achieved = samples/s x the reference's brute-force float64 "
                             "operation count (SURVEY 8d), not executed work -- the float32 pre-filter issues packed "
-                            "float32 (peak 157.3 TFLOP/s) and the block culling skips tests; see `executed`")
+                            "float32 (peak 157.3 TFLOP/s) and the block culling skips tests")
             result_dtype = "f64 (canvas bit-identical to the float64 path)"
         else:
             result_dtype = "f64"
         result = {
-            "metric": "Msamples/s (pixels\u00d7spp/s) on book-1 random_scene", "value": round(value, 2), "unit": "Msamples/s",
+            "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": result_dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
+            "config": {"workload": f"{config_name(W, H, args.spp, max(world, 1))}: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
                                    f"{spp} spp ({args.spp} per GPU), depth {args.depth}",
                        "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
+                       "timed_region": "scene + camera resident in HBM, frame stays on the device (harness contract); "
+                                       "SURVEY 8(d)'s host-canvas region is reported beside it as `host_canvas`",
                        "parallelism": f"row tiles of {args.row_tile} dealt to {max(world, 1)} rank(s)" +
-                                      (" + RCCL all_gather of the framebuffer" if world > 1 else "")},
+                                      (f" + {gather_kind}" if world > 1 else "")},
             "roofline": roof,
         }
         if verified is not None:
             result["gathered_frame_identical_to_single_process"] = verified
+    aux = max(1, min(args.aux_steps, args.steps))
+    if rank == 0 and world == 1 and not args.no_host_leg:
+        # ---- SURVEY 8(d)'s region: what a Nim caller of render() pays (trace_of_radiance.nim:60-64) ----
+        import numpy as np
+        cv = tor.new_canvas(H, W, spp, 2.2)
+        hopt = tor.make_options(seeding=seeding, arith=arith, accel=accel, device=dev_index)
+        tor.render(cv, cam, scene.list(), args.depth, hopt)          # first call: context, scene upload, pinned staging
+        first = tor.last_render_timing()
+        t1 = time.perf_counter()
+        for _ in range(aux):
+            tor.render(cv, cam, scene.list(), args.depth, hopt)
+        dth = time.perf_counter() - t1
+        last = tor.last_render_timing()
+        same = bool(np.array_equal(cv.pixels, frame.cpu().numpy()))
+        hv = total_samples * aux / dth / 1e6
+        result["host_canvas"] = {
+            "value": round(hv, 2), "unit": "Msamples/s", "steps": aux, "ms_per_step": round(dth / aux * 1e3, 3),
+            "region": "tor_render_opt on a host canvas: scene (cached) + camera H2D, kernels, D2H into canvas.pixels "
+                      "(SURVEY 8d; trace_of_radiance.nim:60-64)",
+            "vs_resident": round(hv / value, 4), "canvas_identical_to_resident_frame": same,
+            "first_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in first.items()},
+            "steady_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items()},
+        }
     if rank == 0 and world == 1 and args.accel == "none" and not args.no_accel_leg:
         # secondary legs (never the metric's value): the same frame with the exact accelerations -- bit-identical
         # canvas (tests/test_gpu_parity.py::test_block_culling_never_changes_a_pixel), checked here again
-        ref_frame = frame.shard.clone()
+        ref_frame = frame.clone()
         notes = {"f32": "every ray x every object, through the conservative packed-float32 pre-filter first "
                         "(tor_filter32.hpp); kept objects get the reference's float64 test",
                  "blocks": "SURVEY 8 f4: spatial blocks of 8 objects behind conservative boxes",
                  "blocks+f32": "both"}
         for name in ("f32", "blocks", "blocks+f32"):
             opt2 = tor.make_options(seeding=seeding, arith=arith, row_tile=args.row_tile, accel=ACCEL_BITS[name])
-            ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.data_ptr(), stream)
             torch.cuda.synchronize()
-            same = bool(torch.equal(ref_frame, frame.shard))
+            same = bool(torch.equal(ref_frame, frame))
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.shard.data_ptr(), stream)
+            for _ in range(aux):
+                ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.data_ptr(), stream)
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
-            prof2 = measured_profile(W, H, spp, args.seeding, args.arith, name)
             result["accel_" + name.replace("+", "_")] = {
-                "value": round(total_samples * args.steps / dt2 / 1e6, 2), "unit": "Msamples/s",
-                "traffic": prof2.get("bytes"),
-                "valu_active_frac": (prof2.get("executed") or {}).get("valu_active_frac"),
-                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "canvas_identical_to_brute_force": same,
+                "value": round(total_samples * aux / dt2 / 1e6, 2), "unit": "Msamples/s", "steps": aux,
+                "ms_per_step": round(dt2 / aux * 1e3, 3), "canvas_identical_to_brute_force": same,
+                "from_profile": from_profile(W, H, spp, args.seeding, args.arith, name) or None,
                 "note": notes[name] + "; the metric's value above is the reference's float64 brute-force closest hit"}
-    if args.stats and rank == 0:
-        ctx.set_stats(True)
-        step()
-        torch.cuda.synchronize()
-        st = ctx.last_stats()
-        result["kernel_stats"] = {
-            "hit_queries_per_sample": round(st.hit_queries / max(st.samples, 1), 4),
-            "candidates_per_query": round(st.candidates / max(st.hit_queries, 1), 3),
-            "lane_utilisation": round(st.hit_queries / max(st.lane_slots, 1), 4),
-            "samples": int(st.samples),
-        }
-        ctx.set_stats(False)
+        if args.seeding == "sample":
+            # the reference's own stream layout (what tor_render() runs by default), brute force and with its default accelerations
+            for name, bits in (("pixel_seeding", 0), ("pixel_seeding_default_accel", 3)):
+                opt2 = tor.make_options(seeding=tor.SEED_PIXEL, arith=arith, row_tile=args.row_tile, accel=bits)
+                ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(aux):
+                    ctx.render_device(cam, H, W, spp, 2.2, args.depth, opt2, frame.data_ptr(), stream)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                result[name] = {"value": round(total_samples * aux / dt2 / 1e6, 2), "unit": "Msamples/s", "steps": aux,
+                                "ms_per_step": round(dt2 / aux * 1e3, 3),
+                                "note": "TOR_SEED_PIXEL (render.nim:59-67 streams), " +
+                                        ("float64 brute force" if bits == 0 else "TOR_ACCEL_BLOCKS|TOR_ACCEL_F32 = tor_render()'s default")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds)
     elif rank == 0:

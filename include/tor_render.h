@@ -125,8 +125,20 @@ enum {
                            it cannot rule out get the float64 test                                    */
 };
 
+/* How the row shards of a multi-device tor_render_opt() reach the caller's canvas. */
+enum {
+  TOR_GATHER_AUTO = 0,  /* RCCL when the devices are distinct and librccl loads, else peer copies        */
+  TOR_GATHER_RCCL = 1,  /* single-process RCCL (ncclCommInitAll): every device sends its shard to
+                           devices[0] over xGMI, one de-interleave kernel, one D2H (BASELINE north_star) */
+  TOR_GATHER_PEER = 2,  /* the same with hipMemcpyPeerAsync instead of RCCL                              */
+  TOR_GATHER_HOST = 3   /* no device-side gather: every device copies its rows straight into the
+                           canvas over its own PCIe link (SURVEY 8e "alternative")                       */
+};
+
+#define TOR_MAX_DEVICES 16
+
 typedef struct TorOptions {
-  uint32_t struct_size; /* = sizeof(TorOptions) */
+  uint32_t struct_size; /* = sizeof(TorOptions); the 32-byte round-1 layout (up to `accel`) is accepted too */
   int32_t seeding;      /* TOR_SEED_*  (default TOR_SEED_PIXEL)  */
   int32_t arith;        /* TOR_ARITH_* (default TOR_ARITH_STRICT) */
   int32_t device;       /* HIP device ordinal; -1 = current device */
@@ -134,7 +146,15 @@ typedef struct TorOptions {
    * tiles of row_tile rows; tile t is rendered by shard (t mod shard_count).  The shard's
    * rows are written compactly, in increasing row order.  shard_count <= 1: whole image. */
   int32_t shard_index, shard_count, row_tile;
-  int32_t accel;        /* TOR_ACCEL_* bits (default TOR_ACCEL_NONE) */
+  int32_t accel;        /* TOR_ACCEL_* bits (explicit options: default TOR_ACCEL_NONE) */
+  /* Multi-GPU behind the drop-in (tor_render / tor_render_opt only): device_count > 1 renders the frame on
+   * devices[0 .. device_count) -- one host thread and one HIP stream per entry, entry k renders row shard
+   * (k, device_count, row_tile) -- and assembles it in canvas->pixels (`gather`).  An ordinal may appear more
+   * than once (several contexts on one GPU: how a 1-GPU box tests the path).  shard_index/shard_count/device
+   * must then be left at their defaults.  The canvas is bit-identical for every device list. */
+  int32_t device_count;
+  int32_t gather;       /* TOR_GATHER_* */
+  int32_t devices[TOR_MAX_DEVICES];
 } TorOptions;
 
 /* Status codes (the reference's render() returns void and has no error path; this ABI
@@ -155,16 +175,33 @@ enum {
  * max_depth: int)` -- render.nim:49.  Blocking: canvas.pixels is complete on return (the
  * reference's canvas is complete only after exit(Weave)/syncRoot(Weave),
  * trace_of_radiance.nim:61-63).  Reference semantics: TOR_SEED_PIXEL, TOR_ARITH_STRICT.
- * Wherever options are NULL / absent, the environment variable TOR_DEFAULT_ACCEL (0..3, TOR_ACCEL_* bits)
- * selects the exact accelerations -- a speed knob for hosts that keep the reference's signature; the
- * canvas is bit-identical for every value. */
+ *
+ * A host that keeps the reference's signature cannot pass TorOptions, so tor_render() takes its speed knobs
+ * from the environment -- none of them changes a pixel:
+ *   TOR_DEFAULT_ACCEL = 0..3  TOR_ACCEL_* bits.  Unset: 3 -- both exact accelerations are ON for tor_render()
+ *                             (bit-identical canvases by construction, parity tests and differential fuzzing);
+ *                             0 restores the reference's float64 brute force.
+ *   TOR_DEVICES = "all" | "0,1,2,3"   render on several GPUs (TorOptions.device_count / devices)
+ *   TOR_GATHER  = rccl | peer | host  (TorOptions.gather)
+ * The device scene is cached: a call whose object list is byte-identical to the previous call's (on that
+ * device) uploads nothing (the host pointer is never retained; the library keeps its own copy). */
 TOR_API int tor_render(TorCanvas* canvas, const TorCamera* cam, TorHittableList world,
                        int64_t max_depth);
 
-/* Same with explicit options (NULL = defaults).  With shard_count > 1 only this shard's
+/* tor_render with the HittableList behind a pointer: for FFIs that would rather not pass a 16-byte struct by
+ * value (Nim passes small objects by value and large ones by hidden pointer -- README.md:232-235 -- unless the
+ * type is marked {.bycopy.}; a pointer leaves nothing to the calling convention). */
+TOR_API int tor_render_ptr(TorCanvas* canvas, const TorCamera* cam, const TorHittableList* world, int64_t max_depth);
+
+/* Same with explicit options (NULL = tor_render's defaults).  With shard_count > 1 only this shard's
  * rows of canvas->pixels are written (in place, at their image positions). */
 TOR_API int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList world,
                            int64_t max_depth, const TorOptions* opt);
+
+/* Host-side cost of the last tor_render / tor_render_opt call on this thread, in milliseconds:
+ * out[0] scene upload (0 on a cache hit), out[1] launch + kernels until the device is done, out[2] D2H /
+ * gather into canvas->pixels, out[3] whole call.  out[4] = 1 when the scene came from the cache. */
+TOR_API int tor_last_render_timing(double out[5]);
 
 /* Thread-local description of the last failure (never NULL). */
 TOR_API const char* tor_last_error(void);
@@ -180,7 +217,9 @@ TOR_API int tor_context_create(int32_t device, TorContext** out);
 TOR_API int tor_context_destroy(TorContext* ctx);
 
 /* Flattens the AoS HittableVariant list (hittables_lists.nim:41-46) into the device SoA
- * scene.  The host pointer is not retained. */
+ * scene.  The host pointer is not retained (the context keeps a byte copy: a later upload of an identical
+ * list is a no-op, and the layouts a launch does not use -- the float32 and block-culling variants -- are
+ * only built when a launch first asks for them). */
 TOR_API int tor_scene_upload(TorContext* ctx, TorHittableList world);
 
 /* Number of rows / list of rows shard (index,count,row_tile) owns. rows_out may be NULL. */
@@ -195,6 +234,25 @@ TOR_API int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nro
                               int32_t samples_per_pixel, float gamma_correction,
                               int64_t max_depth, const TorOptions* opt, double* d_pixels,
                               void* hip_stream);
+
+/* ---- multi-process hosts: one process per GPU, the framebuffer gather inside the library (RCCL) ----------
+ * rank 0 calls tor_comm_unique_id and hands the 128 bytes to the other ranks by its own means (bench.py:
+ * torch.distributed broadcast); every rank then calls tor_comm_init_rank on its context (ncclCommInitRank).
+ * tor_render_gather_device = tor_render_device for shard (rank, world, opt->row_tile) + the gather of the row
+ * shards over xGMI + a de-interleave kernel: d_frame (nrows*ncols*3 float64, rows in image order, DEVICE memory)
+ * is complete on `root` (root >= 0: send/recv gather, each rank's own link to the root) or on every rank
+ * (root < 0: ncclAllGather).  Asynchronous on hip_stream.  librccl.so.1 is loaded on first use (dlopen), the
+ * library has no link-time dependency on it. */
+TOR_API int tor_comm_unique_id(uint8_t id_out[128]);
+TOR_API int tor_comm_init_rank(TorContext* ctx, const uint8_t id[128], int32_t rank, int32_t world);
+TOR_API int tor_comm_destroy(TorContext* ctx);
+TOR_API int tor_render_gather_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols,
+                                     int32_t samples_per_pixel, float gamma_correction, int64_t max_depth,
+                                     const TorOptions* opt, int32_t root, double* d_frame, void* hip_stream);
+
+/* Scene-cache counters of a context: out[0] = tor_scene_upload calls, out[1] = calls that found the device
+ * scene up to date (nothing rebuilt, nothing copied), out[2] = device layouts built so far. */
+TOR_API int tor_context_scene_counters(TorContext* ctx, int64_t out[3]);
 
 /* Device-side output stage (io/ppm.nim:15-16 quantiser int(256*clamp(c,0,0.999))):
  * d_pixels (n_rows*ncols*3 float64) -> d_rgb8 (n_rows*ncols*3 bytes), same row order. */
@@ -231,8 +289,11 @@ TOR_API int tor_render_frame_h264(TorContext* ctx, const TorCamera* cam, int32_t
                                   const TorOptions* opt, uint8_t* slice_out, int64_t cap);
 
 /* Timing of the last tor_render_device call on this context, measured with HIP events
- * recorded on the launch stream around the integrator kernel only (ms); blocks until the
- * kernel has finished.  samples_out (nullable) = pixel-samples that launch traced. */
+ * recorded on the launch stream around the integrator kernel only (ms; the SEED_PIXEL cost probe and
+ * the tile sort run before the start event); blocks until the kernel has finished.  samples_out
+ * (nullable) = pixel-samples that launch traced.  All launches of one context that may be in flight
+ * together must use ONE stream (per-launch state lives in a ring of 64 slots; with statistics enabled
+ * launches must not overlap at all). */
 TOR_API int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out);
 /* Mean duration (ms) of the integrator kernel over the last `last_n` tor_render_device calls
  * (at most 64 are remembered), from the same per-launch HIP events. */

@@ -25,7 +25,7 @@ class OracleOptions(C.Structure):
     _fields_ = [
         ("seeding", C.c_int32), ("math", C.c_int32), ("arith", C.c_int32), ("accum", C.c_int32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32), ("threads", C.c_int32),
-        ("collect_stats", C.c_int32), ("row_step", C.c_int32),
+        ("collect_stats", C.c_int32), ("row_step", C.c_int32), ("col_block", C.c_int32),
     ]
 
 
@@ -156,10 +156,10 @@ class RenderResult:
 
 def render(nrows, ncols, spp, cam, objs, max_depth=50, gamma=2.2, seeding=SEED_PIXEL,
            math=MATH_LIBM, arith=ARITH_STRICT, accum=ACCUM_SEQUENTIAL, rows=None, threads=0,
-           collect_stats=False, variant=None, row_step=1) -> RenderResult:
-    """render.nim:49-68 on the CPU."""
+           collect_stats=False, variant=None, row_step=1, col_block=0) -> RenderResult:
+    """render.nim:49-68 on the CPU.  col_block > 0 parallelises over (row, column block) tiles -- same pixels."""
     pixels = np.zeros((nrows, ncols, 3), dtype=np.float64)
-    opt = OracleOptions(seeding, math, arith, accum, 0, nrows, threads, int(collect_stats), int(row_step))
+    opt = OracleOptions(seeding, math, arith, accum, 0, nrows, threads, int(collect_stats), int(row_step), int(col_block))
     if rows is not None:
         opt.row_begin, opt.row_end = rows
     st = OracleStats() if collect_stats else None

@@ -89,6 +89,8 @@ typedef struct {
   int32_t threads;  /* 0 = OpenMP default */
   int32_t collect_stats;
   int32_t row_step; /* render every row_step-th row starting at row_begin (0/1 = all) */
+  int32_t col_block; /* > 0: the parallel loop runs over (row, block of col_block columns) tiles instead of whole rows --
+                        same pixels (every pixel owns its stream, render.nim:59-60), better balance for a few rows */
 } OracleOptions;
 
 typedef struct {
@@ -650,9 +652,15 @@ EXPORT int oracle_render(double* pixels, int32_t nrows, int32_t ncols, int32_t s
   {
     OracleStats local; memset(&local, 0, sizeof local);
     OracleStats* st = (o.collect_stats && stats_out) ? &local : NULL;
+    const int32_t cb = (o.col_block > 0 && o.col_block < ncols) ? o.col_block : ncols;
+    const int32_t n_cb = (ncols + cb - 1) / cb;
+    const int64_t n_sel = (o.row_end > o.row_begin) ? ((int64_t)(o.row_end - o.row_begin) + o.row_step - 1) / o.row_step : 0;
 #pragma omp for schedule(dynamic, 1)
-    for (int32_t row = o.row_begin; row < o.row_end; row += o.row_step) {
-      for (int32_t col = 0; col < ncols; ++col) {
+    for (int64_t tile = 0; tile < n_sel * n_cb; ++tile) {
+      const int32_t row = o.row_begin + (int32_t)(tile / n_cb) * o.row_step;
+      const int32_t col0 = (int32_t)(tile % n_cb) * cb;
+      const int32_t col1 = (col0 + cb < ncols) ? col0 + cb : ncols;
+      for (int32_t col = col0; col < col1; ++col) {
         Rng g;
         if (o.seeding == 0) rng_seed2(&g, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);
         V3 pixel = v3(0, 0, 0);

@@ -88,21 +88,51 @@ def test_sample_seeding_matches_oracle(tor, oracle, ref_scene, ref_camera, golde
     _assert_parity(cv.pixels, z[f"c_1_0_{arith}_0"], exact=False)    # libm oracle: 1e-5
 
 
-def test_c1_reference_image(tor, oracle, ref_scene, ref_camera, golden_dir):
-    """BASELINE config C1 (384x216, 100 spp, depth 50) == trace_of_radiance.nim main().
-    GPU canvas == oracle canvas bit-for-bit, and its PPM quantisation against the reference's
-    own PNG (the kernel's sin/cos are correctly rounded, glibc's are 1 ulp off in ~0.14 % of
-    calls, so a handful of 8-bit channels may differ)."""
+def _png_budget(oracle, ref_scene, ref_camera, golden):
+    """How many 8-bit channels the oracle's two math modes differ in at C1 ON THIS BOX, and whether its pinned
+    (LIBM) mode reproduces the reference PNG here.  The GPU is bit-identical to the PORTABLE mode, so this -- not
+    a fixed allowance -- is what its image may differ from the PNG by (measured: 0 and True)."""
     objs, _ = ref_scene
-    scene, cam = tor.random_scene(0xFACADE), tor.camera()
-    cv = _render(tor, scene, cam, 216, 384, 100)  # tor_render(): reference semantics
-    want = oracle.render(216, 384, 100, ref_camera, objs, seeding=0, math=1, arith=0).pixels
-    _assert_parity(cv.pixels, want)
-    rgb = tor.export_rgb8(cv)
+    libm = oracle.render(216, 384, 100, ref_camera, objs, seeding=0, math=0, arith=0).pixels
+    port = oracle.render(216, 384, 100, ref_camera, objs, seeding=0, math=1, arith=0).pixels
+    q_libm, q_port = oracle.quantize_ppm(libm), oracle.quantize_ppm(port)
+    return libm, port, bool(np.array_equal(q_libm, golden)), int((q_libm != q_port).sum())
+
+
+def test_c1_reference_image(tor, oracle, ref_scene, ref_camera, golden_dir):
+    """BASELINE config C1 (384x216, 100 spp, depth 50) == trace_of_radiance.nim main(), through tor_render() (the
+    reference's signature; exact accelerations on by default) and with the float64 brute force.
+      GPU float64 canvas == oracle(PORTABLE) bit for bit;
+      GPU float64 canvas vs the PINNED oracle mode (LIBM, the one that reproduces the PNG): <= 1e-5 stated,
+        and in fact within a few ulp (the max is printed);
+      GPU 8-bit image vs the reference's PNG: 0 differing channels whenever oracle(LIBM) reproduces the PNG on
+        this box, never more than the oracle's own LIBM-vs-PORTABLE count."""
     g = np.array(Image.open(os.path.join(golden_dir, "book2_motion_blur.png")).convert("RGB"))
-    differ = int((rgb != g).sum())
-    assert differ <= 25, f"{differ} of {g.size} 8-bit channels differ from the reference PNG"
-    assert int(np.abs(rgb.astype(int) - g.astype(int)).max()) <= 8
+    libm, port, libm_is_png, budget = _png_budget(oracle, ref_scene, ref_camera, g)
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    for opts in (None, dict(seeding=tor.SEED_PIXEL, accel=0)):
+        cv = tor.new_canvas(216, 384, 100, 2.2)
+        tor.render(cv, cam, scene.list(), 50, tor.make_options(**opts) if opts else None)
+        _assert_parity(cv.pixels, port)
+        err = float(np.max(np.abs(cv.pixels - libm)))
+        print(f"C1 GPU vs oracle(LIBM): max |delta| = {err:.3e}")
+        assert err <= TOL and err < 1e-12
+        rgb = tor.export_rgb8(cv)
+        differ = int((rgb != g).sum())
+        assert differ <= budget, f"{differ} 8-bit channels differ from the reference PNG (oracle LIBM-vs-PORTABLE: {budget})"
+        if libm_is_png:
+            assert differ == 0, f"{differ} of {g.size} 8-bit channels differ from the reference PNG"
+        # the DEVICE quantiser (io/ppm.nim:15-16) on the same canvas against the PNG and the oracle's quantiser
+        import torch
+        ctx = tor.Context()
+        dev = torch.from_numpy(cv.pixels).cuda()
+        out = torch.empty((216, 384, 3), dtype=torch.uint8, device="cuda")
+        ctx.quantize_rgb8_device(dev.data_ptr(), dev.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        dq = out.cpu().numpy()[::-1]                       # canvas row 0 = bottom scanline (io/ppm.nim:20)
+        assert np.array_equal(dq, oracle.quantize_ppm(cv.pixels))
+        assert int((dq != g).sum()) <= budget and (not libm_is_png or np.array_equal(dq, g))
+        ctx.close()
 
 
 def test_pixel_seeding_cost_ordered_schedule(tor, oracle, ref_scene, ref_camera):
@@ -306,6 +336,8 @@ def test_full_size_properties(tor):
     torch.cuda.synchronize()
     ref = (256 * outs[0].clamp(0.0, 0.999)).to(torch.int32).to(torch.uint8)
     assert torch.equal(rgb, ref)
+    from oracle import oracle as O
+    assert np.array_equal(rgb.cpu().numpy()[::-1], O.quantize_ppm(outs[0].cpu().numpy()))   # io/ppm.nim:14-27 restated in C
     ms, n = ctx.last_kernel_ms()
     assert n == (h // 4 + 0) * 0 + len(tor.shard_rows(h, 8, 3, 4)) * w * spp and ms > 0
     ctx.close()
@@ -352,7 +384,8 @@ def test_c_host_example_reproduces_reference_image(tor, golden_dir, tmp_path):
     assert tok[0] == b"P3" and (int(tok[1]), int(tok[2]), int(tok[3])) == (384, 216, 255)
     rgb = np.array(tok[4:], dtype=np.int64).reshape(216, 384, 3)
     g = np.array(Image.open(os.path.join(golden_dir, "book2_motion_blur.png")).convert("RGB")).astype(np.int64)
-    assert int((rgb != g).sum()) <= 25 and int(np.abs(rgb - g).max()) <= 8
+    differ = int((rgb != g).sum())
+    assert differ == 0, f"{differ} 8-bit channels differ from the reference PNG"
 
 
 def _random_records(rng, n, spread, with_big):
@@ -508,7 +541,10 @@ def test_default_accel_from_environment(tor, monkeypatch):
         tor.render(cv, cam, scene.list(), 50)            # options=None -> tor_render(), the reference's signature
         return cv.pixels.copy()
     monkeypatch.delenv("TOR_DEFAULT_ACCEL", raising=False)
-    base = plain()
-    for v in ("3", "2", "1", "17", "x"):
+    base = plain()                                        # unset: both exact accelerations (the drop-in's default)
+    brute = tor.new_canvas(27, 48, 4, 2.2)
+    tor.render(brute, cam, scene.list(), 50, tor.make_options(accel=0))
+    assert np.array_equal(base, brute.pixels)
+    for v in ("0", "3", "2", "1", "17", "x"):
         monkeypatch.setenv("TOR_DEFAULT_ACCEL", v)
         assert np.array_equal(plain(), base), v

@@ -30,6 +30,8 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 SEED_PIXEL, SEED_SAMPLE = 0, 1
 ARITH_STRICT, ARITH_FUSED = 0, 1
 ACCEL_NONE, ACCEL_BLOCKS, ACCEL_F32 = 0, 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
+MAX_DEVICES = 16
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SPHERE, MOVING_SPHERE = 0, 1
 
@@ -105,7 +107,8 @@ class CanvasStruct(C.Structure):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("seeding", C.c_int32), ("arith", C.c_int32),
                 ("device", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("row_tile", C.c_int32), ("accel", C.c_int32)]
+                ("row_tile", C.c_int32), ("accel", C.c_int32),
+                ("device_count", C.c_int32), ("gather", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES)]
 
 
 class Stats(C.Structure):
@@ -125,6 +128,8 @@ EXPORTED_SYMBOLS = [
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
     "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_slab32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
+    "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
+    "tor_context_scene_counters", "tor_render_ptr",
 ]
 
 _lib = None
@@ -135,13 +140,18 @@ def build(force: bool = False) -> str:
     file lock: the ranks of a multi-GPU launch may all find the library missing at the same time."""
     import fcntl
     src_dir = os.path.join(_HERE, "csrc")
-    with open(os.path.join(src_dir, ".build.lock"), "w") as lock:
+    lock_path = os.path.join(src_dir, ".build.lock")
+    if not os.access(src_dir, os.W_OK):  # read-only install: serialise through the temp dir instead
+        import hashlib
+        import tempfile
+        lock_path = os.path.join(tempfile.gettempdir(), "tor_mi355x_" + hashlib.sha1(src_dir.encode()).hexdigest()[:12] + ".lock")
+    with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if force or not os.path.exists(LIB_PATH):
-                subprocess.run(["make", "-C", src_dir, "-B", "all"], check=True, capture_output=True)
-            else:
-                subprocess.run(["make", "-C", src_dir, "all"], check=True, capture_output=True)
+            cmd = ["make", "-C", src_dir] + (["-B"] if force or not os.path.exists(LIB_PATH) else []) + ["all"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:  # show the compiler's own words
+                raise TorError(-3, f"building libtor_mi355x.so failed ({' '.join(cmd)}):\n{r.stdout[-4000:]}\n{r.stderr[-8000:]}")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
@@ -177,6 +187,7 @@ def lib():
     L.tor_last_error.restype = C.c_char_p
     L.tor_version.restype = C.c_char_p
     L.tor_render.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), HittableList, C.c_int64]
+    L.tor_render_ptr.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), C.POINTER(HittableList), C.c_int64]
     L.tor_render_opt.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), HittableList, C.c_int64,
                                  C.POINTER(Options)]
     L.tor_context_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
@@ -223,6 +234,13 @@ def lib():
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int64]
+    L.tor_last_render_timing.argtypes = [dp]
+    L.tor_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.tor_comm_init_rank.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
+    L.tor_comm_destroy.argtypes = [C.c_void_p]
+    L.tor_render_gather_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int64,
+                                           C.POINTER(Options), C.c_int32, C.c_void_p, C.c_void_p]
+    L.tor_context_scene_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -397,8 +415,29 @@ def new_canvas(height, width, samples_per_pixel, gamma_correction=2.2) -> Canvas
 
 
 def make_options(seeding=SEED_PIXEL, arith=ARITH_STRICT, device=-1, shard_index=0, shard_count=1,
-                 row_tile=1, accel=0) -> Options:
-    return Options(C.sizeof(Options), seeding, arith, device, shard_index, shard_count, row_tile, accel)
+                 row_tile=1, accel=0, devices=None, gather=GATHER_AUTO) -> Options:
+    """TorOptions.  devices: a list of HIP ordinals -> tor_render_opt renders row shard k on devices[k] and
+    assembles the frame in the canvas (`gather`)."""
+    o = Options(C.sizeof(Options), seeding, arith, device, shard_index, shard_count, row_tile, accel)
+    if devices:
+        o.device_count = len(devices)
+        for k, d in enumerate(devices):
+            o.devices[k] = int(d)
+    o.gather = gather
+    return o
+
+
+def last_render_timing() -> dict:
+    """Host-side cost of this thread's last render(): ms for upload, launch+kernels, download/gather, whole call."""
+    t = (C.c_double * 5)()
+    _check(lib().tor_last_render_timing(t))
+    return {"upload_ms": t[0], "render_ms": t[1], "download_ms": t[2], "total_ms": t[3], "scene_cache_hit": bool(t[4])}
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    _check(lib().tor_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def render(canvas: Canvas, cam: Camera, world: HittableList, max_depth: int, options: Options | None = None):
@@ -497,6 +536,26 @@ class Context:
         _check(lib().tor_render_frame_h264(self._h, C.byref(cam), nrows, ncols, spp, gamma, int(max_depth),
                                            C.byref(options) if options is not None else None, buf, n))
         return bytes(buf)
+
+    def scene_counters(self):
+        """(uploads, cache hits, device layouts built)"""
+        out = (C.c_int64 * 3)()
+        _check(lib().tor_context_scene_counters(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def comm_init_rank(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank inside the library (one process per GPU; id from comm_unique_id() of rank 0)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib().tor_comm_init_rank(self._h, buf, rank, world))
+
+    def comm_destroy(self):
+        _check(lib().tor_comm_destroy(self._h))
+
+    def render_gather_device(self, cam: Camera, nrows: int, ncols: int, spp: int, gamma: float, max_depth: int,
+                             options: Options, root: int, d_frame_ptr: int, stream_ptr: int = 0):
+        """This rank's row shard + the RCCL framebuffer gather + de-interleave, asynchronous on the stream."""
+        _check(lib().tor_render_gather_device(self._h, C.byref(cam), nrows, ncols, spp, gamma, int(max_depth),
+                                              C.byref(options), root, C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)))
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

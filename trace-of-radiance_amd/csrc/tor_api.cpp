@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,9 +18,7 @@
 #include <utility>
 #include <vector>
 
-#include "tor_kernels.hpp"
-#include "tor_filter32.hpp"
-#include "tor_scene.hpp"
+#include "tor_context.hpp"
 
 // ---- layout guards: the structs must match what Nim's C backend emits --------
 static_assert(sizeof(TorVec3) == 24, "Vec3 is 3 x float64 (vec3s.nim:12-14)");
@@ -32,23 +31,21 @@ static_assert(sizeof(TorHittableList) == 16, "HittableList (hittables_lists.nim:
 static_assert(sizeof(TorCamera) == 192, "Camera (cameras.nim:15-22)");
 static_assert(sizeof(TorCanvas) == 24, "Canvas (canvas.nim:20-28)");
 static_assert(sizeof(tor::Camera) == sizeof(TorCamera), "device camera mirrors TorCamera");
+static_assert(offsetof(TorOptions, device_count) == 32, "the round-1 TorOptions is a prefix of the current one");
 
 namespace {
-
 thread_local std::string g_last_error = "";
+thread_local double g_last_timing[5] = {0, 0, 0, 0, 0};
+}  // namespace
+
+namespace tor {
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }  // for the host-only sources (tor_mp4.cpp)
 
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-
-}  // namespace
-
-namespace tor {
-void set_last_error(const std::string& msg) { g_last_error = msg; }  // for the host-only sources (tor_mp4.cpp)
-}
-
-namespace {
 
 int fail_hip(hipError_t e, const char* what) {
   std::string m = std::string(what) + ": " + hipGetErrorString(e);
@@ -58,117 +55,57 @@ int fail_hip(hipError_t e, const char* what) {
   return fail(TOR_ERR_HIP, m);
 }
 
-#define HIP_TRY(expr)                                  \
-  do {                                                 \
-    hipError_t e__ = (expr);                           \
-    if (e__ != hipSuccess) return fail_hip(e__, #expr); \
-  } while (0)
-
-struct DeviceBuffer {
-  void* ptr = nullptr;
-  size_t bytes = 0;
-  hipError_t ensure(size_t n) {
-    if (n <= bytes) return hipSuccess;
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
-    hipError_t e = hipMalloc(&ptr, n);
-    if (e == hipSuccess) bytes = n;
-    return e;
+hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* cold_override) {
+  const std::vector<double>& c = cold_override ? *cold_override : lay.cold;
+  struct Part { const void* src; size_t bytes; size_t off; };
+  Part parts[6] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
+                   {lay.movy.data(), lay.movy.size() * 8, 0}, {lay.segs.data(), lay.segs.size() * 8, 0},
+                   {c.data(), c.size() * 8, 0},               {lay.hot32.data(), lay.hot32.size() * 4, 0}};
+  size_t total = 0;
+  for (Part& p : parts) {
+    p.off = total;
+    total += (p.bytes + 255) / 256 * 256 + 256;  // every array keeps a little slack behind it
   }
-  void release() {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
+  std::vector<unsigned char> host(total, 0);
+  for (const Part& p : parts)
+    if (p.bytes > 0) std::memcpy(host.data() + p.off, p.src, p.bytes);
+  hipError_t e = blob.ensure(total);
+  if (e == hipSuccess) e = hipMemcpy(blob.ptr, host.data(), total, hipMemcpyHostToDevice);
+  const char* b = (const char*)blob.ptr;
+  stat = (const double*)(b + parts[0].off);
+  mov = (const double*)(b + parts[1].off);
+  movy = (const double*)(b + parts[2].off);
+  segs = (const double*)(b + parts[3].off);
+  cold = (const double*)(b + parts[4].off);
+  hot32 = (const float*)(b + parts[5].off);
+  n_segs = lay.n_segs;
+  has_f32 = false;
+  for (int s = 0; s < lay.n_segs; ++s) has_f32 = has_f32 || lay.segs[8 * (size_t)s] >= 5.0;
+  return e;
+}
+
+static bool parse_device_list(const char* e, TorOptions& o) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return false;
+  o.device_count = 0;
+  if (std::strcmp(e, "all") == 0) {
+    for (int d = 0; d < count && d < TOR_MAX_DEVICES; ++d) o.devices[o.device_count++] = d;
+    return true;
   }
-};
-
-}  // namespace
-
-namespace {
-
-// device copy of a tor::HostLayout
-struct DeviceLayout {
-  DeviceBuffer stat, mov, movy, segs, cold, hot32;
-  int n_segs = 0;
-  bool has_f32 = false;
-  hipError_t put(const tor::HostLayout& lay, const std::vector<double>* cold_override = nullptr) {
-    auto up = [](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
-      hipError_t e = b.ensure(bytes > 0 ? bytes : 8);
-      if (e == hipSuccess && bytes > 0) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
-      return e;
-    };
-    const std::vector<double>& c = cold_override ? *cold_override : lay.cold;
-    hipError_t e = up(stat, lay.stat.data(), lay.stat.size() * 8);
-    if (e == hipSuccess) e = up(mov, lay.mov.data(), lay.mov.size() * 8);
-    if (e == hipSuccess) e = up(movy, lay.movy.data(), lay.movy.size() * 8);
-    if (e == hipSuccess) e = up(segs, lay.segs.data(), lay.segs.size() * 8);
-    if (e == hipSuccess) e = up(cold, c.data(), c.size() * 8);
-    if (e == hipSuccess) e = up(hot32, lay.hot32.data(), lay.hot32.size() * 4);
-    n_segs = lay.n_segs;
-    has_f32 = false;
-    for (int s = 0; s < lay.n_segs; ++s) has_f32 = has_f32 || lay.segs[8 * (size_t)s] >= 5.0;
-    return e;
+  const char* p = e;
+  while (*p) {
+    char* endp = nullptr;
+    const long v = std::strtol(p, &endp, 10);
+    if (endp == p || v < 0 || v >= count || o.device_count >= TOR_MAX_DEVICES) return false;
+    o.devices[o.device_count++] = (int32_t)v;
+    p = endp;
+    if (*p == ',') ++p;
+    else if (*p) return false;
   }
-  void release() { stat.release(); mov.release(); movy.release(); segs.release(); cold.release(); hot32.release(); }
-};
+  return o.device_count > 0;
+}
 
-// device copy of a tor::HostAccel (TOR_ACCEL_BLOCKS): always-list + spatial blocks
-struct DeviceAccel {
-  DeviceLayout always;  // .cold holds always.cold followed by the spatial objects' cold records
-  DeviceBuffer hot, grp, hot32;
-  void release() { always.release(); hot.release(); grp.release(); hot32.release(); }
-};
-
-}  // namespace
-
-struct TorContext {
-  int device = 0;
-  int num_cus = 0;
-  // scene: [0] float64 loops only, [1] with the TOR_ACCEL_F32 segments
-  DeviceLayout flat[2];
-  tor::F32Options f32;
-  // TOR_ACCEL_BLOCKS layouts (same two variants); bounds travel per launch (ring)
-  tor::HostAccel accel[2];
-  DeviceAccel d_accel[2];
-  DeviceBuffer bnd_ring;
-  size_t bnd_slot_bytes = 0;
-  int64_t n_objects = 0;
-  bool scene_ready = false;
-  // work
-  DeviceBuffer counters;  // [0] work counter, [1..4] stats
-  DeviceBuffer tile_cost, tile_order;  // SEED_PIXEL cost-ordered schedule
-  DeviceBuffer wave_log;  // debug: 8 x u64 per wave (only with stats enabled)
-  DeviceBuffer cam_ring;  // 64 x TorCamera: one slot per in-flight launch (async-safe)
-  // host-side staging of the per-launch data: it must outlive the asynchronous copies
-  TorCamera cam_host[64];
-  std::vector<double> bnd_host[64];
-  std::vector<float> bnd32_host[64];
-  DeviceBuffer scratch;   // for tor_render_opt's device framebuffer
-  DeviceBuffer slice;     // tor_render_frame_h264's device slice buffer
-  bool collect_stats = false;
-  static constexpr int kEventRing = 64;
-  hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
-  int64_t launches = 0;  // timed integrator launches so far
-  bool timing_valid = false;
-  int64_t last_samples = 0;
-  int64_t last_n_waves = 0;
-  // Launch shape, measured on MI355X (profiles/r1_wave_service.txt): waves that share a SIMD get
-  // very unequal service (hardware slot 0 ~38 us per bounce iteration, slot 4 0.6-2 ms), so
-  // extra waves add little throughput and park work in slow waves.  Per seeding mode:
-  //   SAMPLE: 3 workgroups/CU (kernel compiled for <= 168 VGPRs)  -> best throughput
-  //   PIXEL : 2 workgroups/CU (<= 256 VGPRs): a pixel is a sequential chain of spp samples, every
-  //           wave that holds one must get good service; with an exact acceleration the iteration is short
-  //           enough that 3 workgroups/CU win (C2: f32 1768 -> 1900, blocks 1625 -> 1790, both 2133 -> 2350)
-  // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3), TOR_BLOCKS_PER_CU.
-  int max_blocks_per_cu[2][2] = {{2, 3}, {3, 3}};  // [seeding][any TOR_ACCEL_* bit set]
-  int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
-  int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
-};
-
-namespace {
-
-bool valid_options(const TorOptions* opt, TorOptions& o) {
+bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
   o = TorOptions{};
   o.struct_size = sizeof(TorOptions);
   o.seeding = TOR_SEED_PIXEL;
@@ -177,15 +114,31 @@ bool valid_options(const TorOptions* opt, TorOptions& o) {
   o.shard_index = 0;
   o.shard_count = 1;
   o.row_tile = 1;
+  o.gather = TOR_GATHER_AUTO;
+  constexpr uint32_t kV1Size = 32;  // round-1 layout: everything up to and including `accel`
   if (opt) {
-    if (opt->struct_size != sizeof(TorOptions)) return false;
-    o = *opt;
-  } else if (const char* e = std::getenv("TOR_DEFAULT_ACCEL")) {
+    if (opt->struct_size == sizeof(TorOptions)) o = *opt;
+    else if (opt->struct_size == kV1Size) std::memcpy(&o, opt, kV1Size);
+    else return false;
+    o.struct_size = sizeof(TorOptions);
+  } else if (for_drop_in) {
     // tor_render() has the reference's signature and no options: a host that cannot pass TorOptions (the Nim
-    // shim of INTEGRATION.md) opts into the exact accelerations through the environment.  They never change a
-    // pixel, so this is a speed knob only.
-    const int v = std::atoi(e);
-    if (v >= 0 && v <= (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) o.accel = v;
+    // shim of INTEGRATION.md) steers the library through the environment.  None of these changes a pixel.
+    o.accel = TOR_ACCEL_BLOCKS | TOR_ACCEL_F32;  // exact accelerations on by default for the drop-in
+    if (const char* e = std::getenv("TOR_DEFAULT_ACCEL")) {
+      char* endp = nullptr;
+      const long v = std::strtol(e, &endp, 10);
+      if (endp != e && *endp == 0 && v >= 0 && v <= (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) o.accel = (int32_t)v;
+    }
+    if (const char* e = std::getenv("TOR_DEVICES")) {
+      TorOptions t = o;
+      if (parse_device_list(e, t)) o = t;
+    }
+    if (const char* e = std::getenv("TOR_GATHER")) {
+      if (!std::strcmp(e, "rccl")) o.gather = TOR_GATHER_RCCL;
+      else if (!std::strcmp(e, "peer")) o.gather = TOR_GATHER_PEER;
+      else if (!std::strcmp(e, "host")) o.gather = TOR_GATHER_HOST;
+    }
   }
   if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return false;
   if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return false;
@@ -193,16 +146,102 @@ bool valid_options(const TorOptions* opt, TorOptions& o) {
   if (o.shard_count < 1) o.shard_count = 1;
   if (o.row_tile < 1) o.row_tile = 1;
   if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
+  if (o.device_count < 0 || o.device_count > TOR_MAX_DEVICES) return false;
+  if (o.gather < TOR_GATHER_AUTO || o.gather > TOR_GATHER_HOST) return false;
+  if (o.device_count > 1) {
+    if (o.shard_count != 1) return false;  // the device list IS the sharding
+    for (int k = 0; k < o.device_count; ++k)
+      if (o.devices[k] < 0) return false;
+  } else if (o.device_count == 1) {
+    if (o.devices[0] < 0) return false;
+    o.device = o.devices[0];
+  }
   return true;
 }
 
-}  // namespace
+// ---- lazily built device layouts ---------------------------------------------------------------
+int ensure_layouts(TorContext* ctx, int accel) {
+  const TorHittableVariant* objs = (const TorHittableVariant*)ctx->scene_bytes.data();
+  const int64_t n = ctx->n_objects;
+  const bool want_f32 = (accel & TOR_ACCEL_F32) != 0;
+  const bool want_blocks = (accel & TOR_ACCEL_BLOCKS) != 0;
+  if (want_f32 && !ctx->f32_built) {
+    ctx->f32 = f32_options_for(objs, n);
+    ctx->f32_built = true;
+  }
+  auto build_flat = [&](int v) -> int {
+    if (ctx->flat_built[v]) return TOR_OK;
+    std::vector<int64_t> ids((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = i;
+    HostLayout lay;
+    std::string err;
+    if (!build_layout(objs, ids, lay, err, v == 1 ? &ctx->f32 : nullptr)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: " + err);
+    if (n == 0) lay.n_segs = 0;
+    HIP_TRY(ctx->flat[v].put(lay));
+    ctx->flat_built[v] = true;
+    ctx->n_layouts_built += 1;
+    return TOR_OK;
+  };
+  auto build_blocks = [&](int v) -> int {
+    if (ctx->accel_built[v]) return TOR_OK;
+    build_accel(objs, n, ctx->accel[v], v == 1 ? &ctx->f32 : nullptr);
+    ctx->accel_built[v] = true;
+    if (!ctx->accel[v].available) return TOR_OK;
+    ctx->n_layouts_built += 1;
+    auto put = [](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
+      hipError_t e = b.ensure(bytes > 0 ? bytes : 8);
+      if (e == hipSuccess && bytes > 0) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
+      return e;
+    };
+    HIP_TRY(ctx->d_accel[v].always.put(ctx->accel[v].always, &ctx->accel[v].cold));
+    HIP_TRY(put(ctx->d_accel[v].hot, ctx->accel[v].hot.data(), ctx->accel[v].hot.size() * 8));
+    HIP_TRY(put(ctx->d_accel[v].grp, ctx->accel[v].groups.data(), ctx->accel[v].groups.size() * 8));
+    if (ctx->accel[v].sp32) HIP_TRY(put(ctx->d_accel[v].hot32, ctx->accel[v].hot32.data(), ctx->accel[v].hot32.size() * 4));
+    const size_t n_bnd_p = (ctx->accel[v].n_blocks + kPad - 1) / kPad * kPad;
+    const size_t n_super_p = (n_bnd_p / kPad + kPad - 1) / kPad * kPad;
+    // per slot: the float64 boxes, then the same records as float32 (8 floats each)
+    const size_t slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * (8 + 4);
+    if (slot_bytes * TorContext::kRing > ctx->bnd_ring.bytes) {
+      // growing the ring frees the old one: no launch may still be reading it
+      if (ctx->bnd_ring.ptr) HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(ctx->bnd_ring.ensure(slot_bytes * TorContext::kRing));
+    }
+    if (slot_bytes > ctx->bnd_slot_bytes) ctx->bnd_slot_bytes = slot_bytes;
+    return TOR_OK;
+  };
+  int v32 = want_f32 ? 1 : 0;
+  if (want_blocks) {
+    int rc = build_blocks(v32);
+    if (rc != TOR_OK) return rc;
+    // the float32 kernel variant needs float32 block records; otherwise the launch stays on the float64 layouts
+    if (v32 && ctx->accel[1].available && !ctx->accel[1].sp32) {
+      v32 = 0;
+      rc = build_blocks(0);
+      if (rc != TOR_OK) return rc;
+    }
+    if (ctx->accel[v32].available) return TOR_OK;  // the launch uses the always-layout of the accel variant
+  }
+  return build_flat(v32);
+}
+
+}  // namespace tor
+
+using tor::DeviceBuffer;
+using tor::fail;
+using tor::fail_hip;
+using tor::valid_options;
 
 extern "C" {
 
 const char* tor_last_error(void) { return g_last_error.c_str(); }
 
-const char* tor_version(void) { return "tor_mi355x 0.1 (gfx950)"; }
+const char* tor_version(void) { return "tor_mi355x 0.2 (gfx950)"; }
+
+int tor_last_render_timing(double out[5]) {
+  if (!out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_render_timing: out is NULL");
+  for (int k = 0; k < 5; ++k) out[k] = g_last_timing[k];
+  return TOR_OK;
+}
 
 int tor_context_create(int32_t device, TorContext** out) {
   if (!out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_context_create: out is NULL");
@@ -230,9 +269,9 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
     for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
-  e = ctx->counters.ensure(8 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kEventRing * sizeof(TorCamera));
-  for (int i = 0; i < TorContext::kEventRing && e == hipSuccess; ++i) {
+  e = ctx->counters.ensure(TorContext::kRing * 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kRing * sizeof(TorCamera));
+  for (int i = 0; i < TorContext::kRing && e == hipSuccess; ++i) {
     e = hipEventCreate(&ctx->ev_start[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop[i]);
   }
@@ -247,6 +286,8 @@ int tor_context_create(int32_t device, TorContext** out) {
 int tor_context_destroy(TorContext* ctx) {
   if (!ctx) return TOR_OK;
   (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  (void)tor_comm_destroy(ctx);
   for (int v = 0; v < 2; ++v) {
     ctx->flat[v].release();
     ctx->d_accel[v].release();
@@ -255,11 +296,18 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->counters.release();
   ctx->cam_ring.release();
   ctx->wave_log.release();
-  ctx->tile_cost.release();
-  ctx->tile_order.release();
+  for (int i = 0; i < TorContext::kRing; ++i) {
+    ctx->tile_cost[i].release();
+    ctx->tile_order[i].release();
+  }
   ctx->scratch.release();
   ctx->slice.release();
-  for (int i = 0; i < TorContext::kEventRing; ++i) {
+  ctx->gather.release();
+  ctx->frame.release();
+  ctx->staging.release();
+  for (hipEvent_t ev : ctx->chunk_events) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (int i = 0; i < TorContext::kRing; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
     if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
   }
@@ -273,52 +321,45 @@ int tor_context_set_stats(TorContext* ctx, int32_t enable) {
   return TOR_OK;
 }
 
+int tor_context_scene_counters(TorContext* ctx, int64_t out[3]) {
+  if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_context_scene_counters: NULL argument");
+  out[0] = ctx->n_uploads;
+  out[1] = ctx->n_cache_hits;
+  out[2] = ctx->n_layouts_built;
+  return TOR_OK;
+}
+
 // AoS -> SoA.  Objects are partitioned into one static segment and one segment per distinct
 // (time0, time1) pair; closest-hit is order independent (hittables_lists.nim:48-55; ties are
 // broken by the original index carried in the cold record), so the reordering is exact.
+// The context keeps a byte copy of the list: an identical list is a cache hit, and the device layouts are
+// built from the copy when a launch first needs them (ensure_layouts).
 int tor_scene_upload(TorContext* ctx, TorHittableList world) {
   if (!ctx) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: ctx is NULL");
   if (world.len < 0 || (world.len > 0 && !world.objects))
     return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: bad HittableList");
   if (world.len > (int64_t)1 << 24) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: too many objects");
+  ctx->n_uploads += 1;
+  const size_t bytes = (size_t)world.len * sizeof(TorHittableVariant);
+  if (ctx->scene_ready && ctx->n_objects == world.len && ctx->scene_bytes.size() == bytes &&
+      (bytes == 0 || std::memcmp(ctx->scene_bytes.data(), world.objects, bytes) == 0)) {
+    ctx->n_cache_hits += 1;
+    return TOR_OK;
+  }
+  for (int64_t i = 0; i < world.len; ++i) {
+    const TorHittableVariant& h = world.objects[i];
+    if (h.kind != TOR_SPHERE && h.kind != TOR_MOVING_SPHERE) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown HittableVariant kind");
+    const uint8_t mk = h.kind == TOR_SPHERE ? h.u.sphere.material.kind : h.u.moving_sphere.material.kind;
+    if (mk > TOR_DIELECTRIC) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: unknown Material kind");
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   // the scene buffers are about to be overwritten / reallocated: no launch may still be reading them
-  HIP_TRY(hipDeviceSynchronize());
+  if (ctx->scene_ready) HIP_TRY(hipDeviceSynchronize());
   ctx->scene_ready = false;
-  const int64_t n = world.len;
-  std::vector<int64_t> ids((size_t)n);
-  for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = i;
-  ctx->f32 = tor::f32_options_for(world.objects, n);
-  for (int v = 0; v < 2; ++v) {
-    const tor::F32Options* f32 = (v == 1) ? &ctx->f32 : nullptr;
-    tor::HostLayout lay;
-    std::string err;
-    if (!tor::build_layout(world.objects, ids, lay, err, f32)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_scene_upload: " + err);
-    if (n == 0) lay.n_segs = 0;
-    HIP_TRY(ctx->flat[v].put(lay));
-    // optional second level (TOR_ACCEL_BLOCKS): built now, bounds are computed per render call
-    tor::build_accel(world.objects, n, ctx->accel[v], f32);
-    if (ctx->accel[v].available) {
-      auto put = [](DeviceBuffer& b, const std::vector<double>& vec) -> hipError_t {
-        hipError_t e = b.ensure(vec.size() * 8);
-        if (e == hipSuccess) e = hipMemcpy(b.ptr, vec.data(), vec.size() * 8, hipMemcpyHostToDevice);
-        return e;
-      };
-      HIP_TRY(ctx->d_accel[v].always.put(ctx->accel[v].always, &ctx->accel[v].cold));
-      HIP_TRY(put(ctx->d_accel[v].hot, ctx->accel[v].hot));
-      HIP_TRY(put(ctx->d_accel[v].grp, ctx->accel[v].groups));
-      if (ctx->accel[v].sp32) {
-        HIP_TRY(ctx->d_accel[v].hot32.ensure(ctx->accel[v].hot32.size() * 4));
-        HIP_TRY(hipMemcpy(ctx->d_accel[v].hot32.ptr, ctx->accel[v].hot32.data(), ctx->accel[v].hot32.size() * 4, hipMemcpyHostToDevice));
-      }
-      const size_t n_bnd_p = (ctx->accel[v].n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
-      const size_t n_super_p = (n_bnd_p / tor::kPad + tor::kPad - 1) / tor::kPad * tor::kPad;
-      // per slot: the float64 boxes, then the same records as float32 (8 floats each)
-      ctx->bnd_slot_bytes = (8 * (n_bnd_p + 1 + n_super_p + 1)) * (8 + 4);
-      HIP_TRY(ctx->bnd_ring.ensure(ctx->bnd_slot_bytes * TorContext::kEventRing));
-    }
-  }
-  ctx->n_objects = n;
+  ctx->scene_bytes.assign((const unsigned char*)world.objects, (const unsigned char*)world.objects + bytes);
+  ctx->n_objects = world.len;
+  for (int v = 0; v < 2; ++v) ctx->flat_built[v] = ctx->accel_built[v] = false;
+  ctx->f32_built = false;
   ctx->scene_ready = true;
   return TOR_OK;
 }
@@ -349,7 +390,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: need nrows >= 2, ncols >= 2, samples_per_pixel >= 1");
   if (max_depth > 0x7fffffff) max_depth = 0x7fffffff;
   TorOptions o;
-  if (!valid_options(opt, o)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: bad TorOptions");
+  if (!valid_options(opt, o, false)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: bad TorOptions");
+  if (o.device_count > 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: one context renders on one device (device lists: tor_render_opt)");
   hipStream_t stream = (hipStream_t)hip_stream;
   HIP_TRY(hipSetDevice(ctx->device));
 
@@ -360,7 +402,12 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   ctx->last_samples = 0;
   if (npix == 0) return TOR_OK;
 
-  HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long), stream));
+  // a ring slot (events, camera, bounds, counters, tile schedule) is reused every kRing launches: its previous
+  // launch must be done
+  const int slot = (int)(ctx->launches % TorContext::kRing);
+  if (ctx->launches >= TorContext::kRing) HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
+  unsigned long long* const slot_counters = (unsigned long long*)ctx->counters.ptr + (size_t)slot * 8;
+  HIP_TRY(hipMemsetAsync(slot_counters, 0, 8 * sizeof(unsigned long long), stream));
   if (max_depth <= 0 || ctx->n_objects < 0) {
     // render.nim:25: the bounce loop does not run -> every sample is black -> pow(0, g) = 0
     HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
@@ -369,20 +416,25 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
   tor::KParams p{};
+  {
+    const int rc = tor::ensure_layouts(ctx, o.accel);
+    if (rc != TOR_OK) return rc;
+  }
   // TOR_ACCEL_F32 layout variant; with TOR_ACCEL_BLOCKS it needs float32 block records (HostAccel::sp32),
   // otherwise the whole launch stays on the float64 layout
   int v32 = (o.accel & TOR_ACCEL_F32) ? 1 : 0;
   if (v32 && (o.accel & TOR_ACCEL_BLOCKS) && ctx->accel[1].available && !ctx->accel[1].sp32) v32 = 0;
-  auto use_layout = [&](const DeviceLayout& L) {
-    p.stat = (const double*)L.stat.ptr;
-    p.mov = (const double*)L.mov.ptr;
-    p.movy = (const double*)L.movy.ptr;
-    p.segs = (const double*)L.segs.ptr;
-    p.cold = (const double*)L.cold.ptr;
-    p.hot32 = L.has_f32 ? (const float*)L.hot32.ptr : nullptr;
+  auto use_layout = [&](const tor::DeviceLayout& L) {
+    p.stat = L.stat;
+    p.mov = L.mov;
+    p.movy = L.movy;
+    p.segs = L.segs;
+    p.cold = L.cold;
+    p.hot32 = L.has_f32 ? L.hot32 : nullptr;
     p.n_segs = L.n_segs;
   };
-  use_layout(ctx->flat[v32]);
+  const bool blocks_avail = (o.accel & TOR_ACCEL_BLOCKS) && ctx->accel_built[v32] && ctx->accel[v32].available;
+  if (!blocks_avail) use_layout(ctx->flat[v32]);
   for (int k = 0; k < 3; ++k) p.org[k] = ctx->f32.origin[k];
   p.bnd = nullptr;
   p.spatial_base = 0;
@@ -390,23 +442,26 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.sgrp = nullptr;
   p.shot_lds_doubles = 0;
   p.shot_stride = 8;
-  const int slot = (int)(ctx->launches % TorContext::kEventRing);
-  // a ring slot (events, camera, bounds) is reused every 64 launches: its previous launch must be done
-  if (ctx->launches >= TorContext::kEventRing) HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
   std::vector<double>& bnd_host = ctx->bnd_host[slot];
   bool use_accel = false;
   int stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
   const tor::HostAccel& hacc = ctx->accel[v32];
-  if ((o.accel & TOR_ACCEL_BLOCKS) && hacc.available) {
+  if (blocks_avail) {
     // rays carry the camera's shutter times, or 0 after a metal / dielectric bounce (rays.nim:19)
     const double t_lo = std::fmin(0.0, std::fmin(cam->shutter_open, cam->shutter_close));
     const double t_hi = std::fmax(0.0, std::fmax(cam->shutter_open, cam->shutter_close));
     use_accel = tor::compute_block_bounds(hacc, t_lo, t_hi, bnd_host);
+    if (!use_accel) {  // non-finite ray-time range: brute force over the flat layout
+      const int rc = tor::ensure_layouts(ctx, o.accel & ~TOR_ACCEL_BLOCKS);
+      if (rc != TOR_OK) return rc;
+      use_layout(ctx->flat[v32]);
+    }
   }
   if (use_accel) {
     use_layout(ctx->d_accel[v32].always);
     p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
     p.spatial_base = (int)hacc.spatial_base;
+    p.n_super = (int)(((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) / tor::kPad);
     p.shot = (const double*)ctx->d_accel[v32].hot.ptr;
     p.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
     p.shot_stride = hacc.hot_stride;
@@ -456,8 +511,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   const long long resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
   p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
-  p.work_counter = (unsigned long long*)ctx->counters.ptr;
-  p.stats = ctx->collect_stats ? (unsigned long long*)ctx->counters.ptr + 1 : nullptr;
+  p.work_counter = slot_counters;
+  p.stats = ctx->collect_stats ? slot_counters + 1 : nullptr;
   p.out = d_pixels;
 
   long long waves;
@@ -498,34 +553,37 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     if (p.bnd32)
       HIP_TRY(hipMemcpyAsync((void*)p.bnd32, ctx->bnd32_host[slot].data(), ctx->bnd32_host[slot].size() * 4, hipMemcpyHostToDevice, stream));
   }
-  HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
   if (o.seeding == TOR_SEED_PIXEL && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && n_tiles > 1) {
     // Cost-ordered schedule: a 2-spp probe (per-sample streams; it only counts closest-hit queries
     // per tile, it never touches the canvas) + a counting sort; ~2/spp of extra work.
-    HIP_TRY(ctx->tile_cost.ensure((size_t)n_tiles * 4));
-    HIP_TRY(ctx->tile_order.ensure((size_t)n_tiles * 4));
-    HIP_TRY(hipMemsetAsync(ctx->tile_cost.ptr, 0, (size_t)n_tiles * 4, stream));
+    DeviceBuffer& tile_cost = ctx->tile_cost[slot];
+    DeviceBuffer& tile_order = ctx->tile_order[slot];
+    HIP_TRY(tile_cost.ensure((size_t)n_tiles * 4));
+    HIP_TRY(tile_order.ensure((size_t)n_tiles * 4));
+    HIP_TRY(hipMemsetAsync(tile_cost.ptr, 0, (size_t)n_tiles * 4, stream));
     tor::KParams pp = p;
     pp.spp = 2;
     pp.total_work = (unsigned long long)npix * 2ull;
     pp.chunk = 256;
-    pp.work_counter = (unsigned long long*)ctx->counters.ptr + 5;
+    pp.work_counter = slot_counters + 5;
     pp.stats = nullptr;
     pp.wave_log = nullptr;
     pp.out = nullptr;
-    pp.tile_cost = (unsigned*)ctx->tile_cost.ptr;
+    pp.tile_cost = (unsigned*)tile_cost.ptr;
     long long pw = (long long)((pp.total_work + 63) / 64);
     const long long pres = (long long)ctx->num_cus * 3 * (tor::kThreads / 64);
     if (pw > pres) pw = pres;
     const int pblocks = (int)((pw + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
     pp.n_waves = (unsigned)(pblocks * (tor::kThreads / 64));
     HIP_TRY(tor::launch_probe(pp, pblocks, stream));
-    HIP_TRY(tor::launch_tile_order((const unsigned*)ctx->tile_cost.ptr, (unsigned*)ctx->tile_order.ptr, (int)n_tiles, stream));
-    p.order = (const unsigned*)ctx->tile_order.ptr;
+    HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned*)tile_order.ptr, (int)n_tiles, stream));
+    p.order = (const unsigned*)tile_order.ptr;
   }
+  HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
   HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));
   HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
   ctx->launches += 1;
+  ctx->last_slot = slot;
   ctx->timing_valid = true;
   ctx->last_samples = (int64_t)npix * spp;
   // canvas.nim:47-54
@@ -628,7 +686,7 @@ int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out) {
   if (!ctx || !ms_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_kernel_ms: NULL argument");
   if (!ctx->timing_valid) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_kernel_ms: no timed launch");
   HIP_TRY(hipSetDevice(ctx->device));
-  const int slot = (int)((ctx->launches - 1) % TorContext::kEventRing);
+  const int slot = (int)((ctx->launches - 1) % TorContext::kRing);
   HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
   HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev_start[slot], ctx->ev_stop[slot]));
   if (samples_out) *samples_out = ctx->last_samples;
@@ -641,10 +699,10 @@ int tor_kernel_ms_mean(TorContext* ctx, int32_t last_n, float* mean_ms_out, int3
   HIP_TRY(hipSetDevice(ctx->device));
   int64_t n = last_n;
   if (n > ctx->launches) n = ctx->launches;
-  if (n > TorContext::kEventRing) n = TorContext::kEventRing;
+  if (n > TorContext::kRing) n = TorContext::kRing;
   double sum = 0.0;
   for (int64_t k = 0; k < n; ++k) {
-    const int slot = (int)((ctx->launches - 1 - k) % TorContext::kEventRing);
+    const int slot = (int)((ctx->launches - 1 - k) % TorContext::kRing);
     float ms = 0.f;
     HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
@@ -671,7 +729,7 @@ int tor_last_stats(TorContext* ctx, TorStats* out) {
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipDeviceSynchronize());
   unsigned long long h[8];
-  HIP_TRY(hipMemcpy(h, ctx->counters.ptr, sizeof h, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(h, (unsigned long long*)ctx->counters.ptr + (size_t)ctx->last_slot * 8, sizeof h, hipMemcpyDeviceToHost));
   out->hit_queries = h[1];
   out->object_tests = h[1] * (uint64_t)ctx->n_objects;
   out->candidates = h[2];
@@ -684,14 +742,44 @@ int tor_last_stats(TorContext* ctx, TorStats* out) {
 // ---- the drop-in: host canvas in, host canvas out ---------------------------------------
 
 static std::mutex g_ctx_mutex;
-static std::map<int, TorContext*> g_default_ctx;  // one cached context per device
+static std::map<std::pair<int, int>, TorContext*> g_default_ctx;  // cached contexts per (device, replica)
+
+}  // extern "C"
+
+namespace tor {
+int default_context(int device, int replica, TorContext** out) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  TorContext*& ctx = g_default_ctx[{device, replica}];
+  if (!ctx) {
+    int rc = tor_context_create(device, &ctx);
+    if (rc != TOR_OK) { ctx = nullptr; return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { tor_context_destroy(ctx); ctx = nullptr; return fail_hip(e, "hipStreamCreate"); }
+  }
+  *out = ctx;
+  return TOR_OK;
+}
+}  // namespace tor
+
+extern "C" {
+
+static std::mutex g_render_mutex;  // the drop-in is callable from one host thread at a time
 
 int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, int64_t max_depth,
                    const TorOptions* opt) {
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+  const clk::time_point t_call = clk::now();
   if (!canvas || !cam || !canvas->pixels) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: NULL argument");
   TorOptions o;
-  if (!valid_options(opt, o)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: bad TorOptions");
-  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  if (!valid_options(opt, o, true)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: bad TorOptions");
+  std::lock_guard<std::mutex> lock(g_render_mutex);
+  for (double& t : g_last_timing) t = 0.0;
+  if (o.device_count > 1) {
+    const int rc = tor::render_multi_device(canvas, cam, world, max_depth, o, g_last_timing);
+    g_last_timing[3] = ms_since(t_call);
+    return rc;
+  }
   int device = o.device;
   if (device < 0) {
     int count = 0;
@@ -701,34 +789,49 @@ int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList worl
                                          "); libtor_mi355x has no CPU fallback");
     HIP_TRY(hipGetDevice(&device));
   }
-  TorContext*& ctx = g_default_ctx[device];
-  if (!ctx) {
-    int rc = tor_context_create(device, &ctx);
-    if (rc != TOR_OK) { ctx = nullptr; return rc; }
-  }
-  int rc = tor_scene_upload(ctx, world);
+  TorContext* ctx = nullptr;
+  int rc = tor::default_context(device, 0, &ctx);
   if (rc != TOR_OK) return rc;
+  clk::time_point t0 = clk::now();
+  const int64_t hits_before = ctx->n_cache_hits;
+  rc = tor_scene_upload(ctx, world);
+  if (rc != TOR_OK) return rc;
+  g_last_timing[4] = ctx->n_cache_hits > hits_before ? 1.0 : 0.0;
+  {
+    // layouts are built here (not inside the timed kernel section) so that out[0] is the whole upload cost
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = tor::ensure_layouts(ctx, o.accel);
+    if (rc != TOR_OK) return rc;
+  }
+  g_last_timing[0] = ms_since(t0);
+  t0 = clk::now();
   const int32_t nrows = canvas->nrows, ncols = canvas->ncols;
   std::vector<int32_t> rows((size_t)(nrows > 0 ? nrows : 0));
   const int32_t local_rows = tor_shard_rows(nrows, o.row_tile, o.shard_index, o.shard_count, rows.data());
-  const size_t row_bytes = (size_t)ncols * 24;
-  HIP_TRY(ctx->scratch.ensure((size_t)(local_rows > 0 ? local_rows : 1) * row_bytes));
+  const size_t row_bytes = (size_t)(ncols > 0 ? ncols : 0) * 24;
+  HIP_TRY(ctx->scratch.ensure((size_t)(local_rows > 0 ? local_rows : 1) * (row_bytes > 0 ? row_bytes : 24)));
   rc = tor_render_device(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction,
-                         max_depth, &o, (double*)ctx->scratch.ptr, nullptr);
+                         max_depth, &o, (double*)ctx->scratch.ptr, ctx->stream);
   if (rc != TOR_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  if (o.shard_count <= 1) {
-    HIP_TRY(hipMemcpy(canvas->pixels, ctx->scratch.ptr, (size_t)nrows * row_bytes, hipMemcpyDeviceToHost));
-  } else {
-    for (int32_t lr = 0; lr < local_rows; ++lr)
-      HIP_TRY(hipMemcpy((char*)canvas->pixels + (size_t)rows[lr] * row_bytes,
-                        (char*)ctx->scratch.ptr + (size_t)lr * row_bytes, row_bytes, hipMemcpyDeviceToHost));
-  }
+  const bool want_split = std::getenv("TOR_TIMING_SPLIT") != nullptr;
+  if (want_split) HIP_TRY(hipStreamSynchronize(ctx->stream));  // otherwise the D2H simply queues behind the kernels
+  g_last_timing[1] = ms_since(t0);
+  t0 = clk::now();
+  rc = tor::download_rows(ctx, ctx->scratch.ptr, local_rows, row_bytes, o.shard_count > 1 ? rows.data() : nullptr,
+                          (char*)canvas->pixels, ctx->stream);
+  if (rc != TOR_OK) return rc;
+  g_last_timing[2] = ms_since(t0);
+  g_last_timing[3] = ms_since(t_call);
   return TOR_OK;
 }
 
 int tor_render(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, int64_t max_depth) {
   return tor_render_opt(canvas, cam, world, max_depth, nullptr);
+}
+
+int tor_render_ptr(TorCanvas* canvas, const TorCamera* cam, const TorHittableList* world, int64_t max_depth) {
+  if (!world) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_ptr: world is NULL");
+  return tor_render_opt(canvas, cam, *world, max_depth, nullptr);
 }
 
 // Debug view of the TOR_ACCEL_BLOCKS layout (host only, no device needed): for the given object list and

@@ -1,0 +1,167 @@
+// tor_context.hpp -- private state behind the opaque TorContext of include/tor_render.h, shared by the
+// translation units of the C-ABI layer (tor_api.cpp: single-device entry points; tor_multi.cpp: canvas
+// download, multi-device tor_render_opt, RCCL gather).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/tor_render.h"
+#include "tor_filter32.hpp"
+#include "tor_kernels.hpp"
+#include "tor_scene.hpp"
+
+namespace tor {
+
+int fail(int code, const std::string& msg);           // sets tor_last_error(), returns code
+int fail_hip(hipError_t e, const char* what);         // maps a HIP error to a TOR_ERR_* status
+
+#define HIP_TRY(expr)                                        \
+  do {                                                       \
+    hipError_t e__ = (expr);                                 \
+    if (e__ != hipSuccess) return ::tor::fail_hip(e__, #expr); \
+  } while (0)
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&ptr, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+// page-locked host staging (D2H lands here at PCIe speed; worker threads move it into the caller's pageable canvas)
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    hipError_t e = hipHostMalloc(&ptr, n, hipHostMallocDefault);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+// device copy of a tor::HostLayout: ONE allocation, one H2D copy; the arrays sit at 256-byte aligned offsets
+struct DeviceLayout {
+  DeviceBuffer blob;
+  const double *stat = nullptr, *mov = nullptr, *movy = nullptr, *segs = nullptr, *cold = nullptr;
+  const float* hot32 = nullptr;
+  int n_segs = 0;
+  bool has_f32 = false;
+  hipError_t put(const HostLayout& lay, const std::vector<double>* cold_override = nullptr);
+  void release() { blob.release(); }
+};
+
+// device copy of a tor::HostAccel (TOR_ACCEL_BLOCKS): always-list + spatial blocks
+struct DeviceAccel {
+  DeviceLayout always;  // .cold holds always.cold followed by the spatial objects' cold records
+  DeviceBuffer hot, grp, hot32;
+  void release() { always.release(); hot.release(); grp.release(); hot32.release(); }
+};
+
+struct RcclComm;  // tor_multi.cpp
+
+}  // namespace tor
+
+struct TorContext {
+  static constexpr int kRing = 64;  // per-launch slots: events, camera, bounds, counters, tile schedule
+  int device = 0;
+  int num_cus = 0;
+  // ---- scene: a byte copy of the caller's list (cache key + source of the lazily built layouts) ----
+  std::vector<unsigned char> scene_bytes;
+  int64_t n_objects = 0;
+  bool scene_ready = false;
+  int64_t n_uploads = 0, n_cache_hits = 0, n_layouts_built = 0;
+  // [0] float64 loops only, [1] with the TOR_ACCEL_F32 segments; built on first use
+  tor::DeviceLayout flat[2];
+  bool flat_built[2] = {false, false};
+  tor::F32Options f32;
+  bool f32_built = false;
+  // TOR_ACCEL_BLOCKS layouts (same two variants); bounds travel per launch (ring)
+  tor::HostAccel accel[2];
+  tor::DeviceAccel d_accel[2];
+  bool accel_built[2] = {false, false};
+  tor::DeviceBuffer bnd_ring;
+  size_t bnd_slot_bytes = 0;
+  // ---- per-launch state ----
+  tor::DeviceBuffer counters;                      // kRing x 8 u64: [0] work counter, [1..4] stats, [5] probe counter
+  tor::DeviceBuffer tile_cost[kRing], tile_order[kRing];  // SEED_PIXEL cost-ordered schedule
+  tor::DeviceBuffer wave_log;                      // debug: 8 x u64 per wave (only with stats enabled)
+  tor::DeviceBuffer cam_ring;                      // kRing x TorCamera
+  TorCamera cam_host[kRing];                       // host staging must outlive the asynchronous copies
+  std::vector<double> bnd_host[kRing];
+  std::vector<float> bnd32_host[kRing];
+  hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
+  int64_t launches = 0;  // timed integrator launches so far
+  bool timing_valid = false;
+  int64_t last_samples = 0;
+  int64_t last_n_waves = 0;
+  int last_slot = 0;
+  bool collect_stats = false;
+  // ---- host-canvas entry points ----
+  tor::DeviceBuffer scratch;   // tor_render_opt's device framebuffer (this device's shard)
+  tor::DeviceBuffer slice;     // tor_render_frame_h264's device slice buffer
+  tor::DeviceBuffer gather;    // root of a multi-device render / RCCL gather: the ranks' shards, rank-major
+  tor::DeviceBuffer frame;     // ... de-interleaved frame (multi-device tor_render_opt)
+  tor::PinnedBuffer staging;   // D2H target
+  std::vector<hipEvent_t> chunk_events;
+  hipStream_t stream = nullptr;  // own stream of the host-canvas entry points (created on first use)
+  tor::RcclComm* comm = nullptr; // tor_comm_init_rank
+  // Launch shape, measured on MI355X (profiles/r1_wave_service.txt): waves that share a SIMD get
+  // very unequal service (hardware slot 0 ~38 us per bounce iteration, slot 4 0.6-2 ms), so
+  // extra waves add little throughput and park work in slow waves.  Per seeding mode:
+  //   SAMPLE: 3 workgroups/CU (kernel compiled for <= 168 VGPRs)  -> best throughput
+  //   PIXEL : 2 workgroups/CU (<= 256 VGPRs): a pixel is a sequential chain of spp samples, every
+  //           wave that holds one must get good service; with an exact acceleration the iteration is short
+  //           enough that 3 workgroups/CU win (C2: f32 1768 -> 1900, blocks 1625 -> 1790, both 2133 -> 2350)
+  // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3), TOR_BLOCKS_PER_CU.
+  int max_blocks_per_cu[2][2] = {{2, 3}, {3, 3}};  // [seeding][any TOR_ACCEL_* bit set]
+  int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
+  int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
+};
+
+namespace tor {
+
+// Options with defaults applied; false when malformed.  `for_drop_in`: NULL options take tor_render()'s
+// environment defaults (TOR_DEFAULT_ACCEL, TOR_DEVICES, TOR_GATHER).
+bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in);
+
+// Makes sure the layouts a launch with (accel bits) needs exist on the device (built from scene_bytes).
+int ensure_layouts(TorContext* ctx, int accel);
+
+// Copies n_rows compact rows of row_bytes from device memory (on ctx's device, ready on `stream`) into host
+// memory: row k lands at dst + rows[k] * row_bytes (rows == nullptr: k * row_bytes).  D2H in chunks into the
+// context's pinned staging, worker threads move the chunks on while later chunks are still in flight.  Blocking.
+int download_rows(TorContext* ctx, const void* d_src, int64_t n_rows, size_t row_bytes, const int32_t* rows,
+                  char* dst, hipStream_t stream);
+
+// default (cached) context of the host-canvas entry points: one per (device, replica)
+int default_context(int device, int replica, TorContext** out);
+
+int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, int64_t max_depth,
+                        const TorOptions& o, double timing_ms[5]);
+
+}  // namespace tor

@@ -453,7 +453,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 m = (m << 1) | slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
                                           (f2v){rec[8 * j + 4], rec[8 * j + 5]});
               rec += 8 * kBlock;
-              m |= r32.wild;
+              // a 'wild' ray (outside the float32 filter's guarded ranges) enters every box -- every REAL box: the
+              // padding entries of the super-box segment have no block boxes or records behind them
+              unsigned wild = r32.wild;
+              if (seg_kind == 4) {
+                const int n_valid = p.n_super - i;  // bit (7 - j) <-> record i + j
+                wild &= (n_valid >= kBlock) ? 0xffu : ((n_valid <= 0) ? 0u : ((0xff00u >> n_valid) & 0xffu));
+              }
+              m |= wild;
               q[qn * 64] = ((seg_kind == 3) ? 0x80000000u : 0x40000000u) | ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
@@ -1008,6 +1015,21 @@ __global__ __launch_bounds__(256) void encode_ipcm_kernel(const double* pixels, 
   }
 }
 
+// Multi-GPU assembly: the shards arrive rank-major and compact; put every row at its image position.
+// One thread per float64 value; HBM-bound copy (48 B per pixel).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* gathered, double* frame, int nrows, int ncols,
+                                                          int row_tile, int shard_count, long long shard_stride) {
+  const long long row_values = (long long)ncols * 3;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)nrows * row_values) return;
+  const int row = (int)(i / row_values);
+  const long long within_row = i - (long long)row * row_values;
+  const int tile = row / row_tile;
+  const int shard = tile % shard_count;
+  const int local_row = (tile / shard_count) * row_tile + (row - tile * row_tile);
+  frame[i] = gathered[(long long)shard * shard_stride + (long long)local_row * row_values + within_row];
+}
+
 __global__ void selftest_kernel(int op, const double* x, const double* y, double* out0, double* out1,
                                 long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1094,6 +1116,15 @@ hipError_t launch_encode_ipcm(const double* pixels, int nrows, int ncols, uint8_
   if (n_mb <= 0) return hipSuccess;
   hipLaunchKernelGGL(encode_ipcm_kernel, dim3((unsigned)n_mb), dim3(256), 0, stream, pixels, nrows, ncols, out, plane_y,
                      plane_cb, plane_cr);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const double* gathered, double* frame, int nrows, int ncols, int row_tile, int shard_count,
+                              long long shard_stride, hipStream_t stream) {
+  const long long n = (long long)nrows * ncols * 3;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gathered, frame, nrows, ncols,
+                     row_tile, shard_count, shard_stride);
   return hipGetLastError();
 }
 

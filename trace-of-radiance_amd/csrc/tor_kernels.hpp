@@ -53,6 +53,8 @@ struct KParams {
   int bnd32_lds_floats;   // > 0: the block boxes (two-level scenes: the per-lane descent reads them) are staged in LDS too
   double sp_t0, sp_dt;    // the spatial movers' time group
   int spatial_base;    // first cold slot of the spatial blocks: block b owns cold[spatial_base + 8b .. +8)
+  int n_super;         // two-level scenes: number of real super boxes (the kind-4 segment is padded to 8; the padding
+                       // entries have no block boxes / records behind them and must never be entered)
   int n_segs;
   int nrows, ncols, spp, max_depth;
   int shard_index, shard_count, row_tile;
@@ -80,6 +82,10 @@ hipError_t launch_finalize(double* pixels, long long n_values, double scale, dou
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
 hipError_t launch_encode_ipcm(const double* pixels, int nrows, int ncols, uint8_t* out, uint8_t* plane_y,
                               uint8_t* plane_cb, uint8_t* plane_cr, hipStream_t stream);
+// multi-GPU assembly: gathered = shard_count slots of shard_stride float64, slot k = shard k's rows (compact, in
+// increasing row order); frame = nrows x ncols x 3 float64 in image order (tor_shard_rows' mapping, inverted)
+hipError_t launch_gather_rows(const double* gathered, double* frame, int nrows, int ncols, int row_tile, int shard_count,
+                              long long shard_stride, hipStream_t stream);
 hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
                            hipStream_t stream);
 
