@@ -112,7 +112,9 @@ def from_profile(W, H, spp, seeding, arith, accel="none"):
             t = json.load(f)
         e = dict(t[f"{W}x{H}x{spp}:{seeding}:{arith}" + ("" if accel == "none" else ":" + accel)])
         e["_what"] = "replayed from committed rocprofv3 summaries (profiles/), NOT measured in this run"
-        e["_profiles_commit"] = git_head()
+        commit = git_head()
+        if commit:
+            e["_profiles_commit"] = commit
         return e
     except Exception:
         return {}
@@ -200,11 +202,13 @@ def cpu_baseline(width, height, spp, depth, target_seconds):
     except Exception as e:  # noqa
         png_note = f"not checked: {e!r}"
     rate = 216 * 384 * 100 / max(c1_dt, 1e-6)
-    want_rows = int(min(height, max(cores, rate * target_seconds / (width * spp))))
+    # a bounded sample of the bench frame: evenly spaced rows, parallelised over (row, 16-column) tiles so that a
+    # few rows still load every core (Weave, too, splits rows and then columns)
+    want_rows = int(min(height, max(4, rate * target_seconds / (width * spp))))
     step = max(1, height // max(want_rows, 1))
     rows = len(range(0, height, step))
     t = time.perf_counter()
-    O.render(height, width, spp, cam, objs, max_depth=depth, row_step=step)
+    O.render(height, width, spp, cam, objs, max_depth=depth, row_step=step, col_block=16)
     dt = time.perf_counter() - t
     samples = rows * width * spp
     model = "unknown"
@@ -220,7 +224,7 @@ def cpu_baseline(width, height, spp, depth, target_seconds):
         "value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"every {step}th row ({rows} of {height} rows) of the {width}x{height}x{spp}spp frame, "
                   f"depth {depth}: {samples / 1e6:.1f} Msamples in {dt:.1f} s; oracle/tor_oracle.c faithful mode "
-                  f"(seed(row,col) streams, libm, -ffp-contract=off), OpenMP schedule(dynamic,1) over rows",
+                  f"(seed(row,col) streams, libm, -ffp-contract=off), OpenMP schedule(dynamic,1) over (row, 16-column) tiles",
         "cpu_model": model,
         "c1": {"workload": "BASELINE configs[0]: 384x216, 100 spp, depth 50 (trace_of_radiance.nim main())",
                "value": round(216 * 384 * 100 / c1_dt / 1e6, 4), "seconds": round(c1_dt, 3),
