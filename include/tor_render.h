@@ -137,6 +137,8 @@ enum {
 
 #define TOR_MAX_DEVICES 16
 
+enum { TOR_PIXEL_KERNEL_AUTO = 0, TOR_PIXEL_KERNEL_LANE = 1, TOR_PIXEL_KERNEL_WAVE = 2 };
+
 typedef struct TorOptions {
   uint32_t struct_size; /* = sizeof(TorOptions); the 32-byte round-1 layout (up to `accel`) is accepted too */
   int32_t seeding;      /* TOR_SEED_*  (default TOR_SEED_PIXEL)  */
@@ -155,6 +157,11 @@ typedef struct TorOptions {
   int32_t device_count;
   int32_t gather;       /* TOR_GATHER_* */
   int32_t devices[TOR_MAX_DEVICES];
+  /* TOR_SEED_PIXEL only: which kernel walks the pixel chains (same canvas either way).
+   * TOR_PIXEL_KERNEL_AUTO: one wave per pixel on small frames (<= 163840 pixels per device; TOR_COOP_MAX_PIXELS),
+   * one lane per pixel otherwise.  LANE / WAVE force one of them (WAVE falls back to LANE when the scene does not
+   * fit LDS). */
+  int32_t pixel_kernel;
 } TorOptions;
 
 /* Status codes (the reference's render() returns void and has no error path; this ABI

@@ -338,3 +338,61 @@ def test_wild_rays_never_enter_padding_super_boxes(tor):
                 tor.render(cv, cam, scene.list(), 6, tor.make_options(seeding=seeding, accel=accel))
                 assert np.array_equal(cv.pixels, base.pixels), (look_from, seeding, accel)
         assert base.pixels.std() > 1e-3
+
+
+def test_wave_per_pixel_kernel_matches_lane_kernel_and_oracle(tor, oracle, ref_scene, ref_camera):
+    """TOR_SEED_PIXEL has two kernels (TorOptions.pixel_kernel): one LANE per pixel chain (large frames) and one
+    WAVE per pixel chain with the object loop split across the 64 lanes (small frames, where the chain latency
+    binds).  Same canvas, bit for bit, and == oracle: random_scene, STRICT and FUSED, row shards, depth limits,
+    the edge-case scene (time groups, duplicates -> tie to the lowest index, hollow sphere, time0 == time1), a
+    1300-object scene (one workgroup per CU of LDS) and a 2100-object scene (does not fit LDS: WAVE falls back)."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    K = (tor.PIXEL_KERNEL_LANE, tor.PIXEL_KERNEL_WAVE)
+
+    def both(scene_, cam_, h, w, spp, depth=50, **opt):
+        out = []
+        for k in K:
+            cv = tor.new_canvas(h, w, spp, 2.2)
+            tor.render(cv, cam_, scene_.list(), depth, tor.make_options(seeding=tor.SEED_PIXEL, pixel_kernel=k, **opt))
+            out.append(cv.pixels)
+        assert np.array_equal(out[0], out[1]), f"lane and wave kernels differ in {(out[0] != out[1]).sum()} values"
+        return out[1]
+
+    for arith in (0, 1):
+        got = both(scene, cam, 36, 64, 16, arith=arith)
+        _exact(got, oracle.render(36, 64, 16, ref_camera, objs, seeding=0, math=1, arith=arith).pixels)
+    got = both(scene, cam, 37, 45, 33, shard_index=1, shard_count=3, row_tile=4)
+    rows = tor.shard_rows(37, 4, 1, 3)
+    _exact(got[rows], oracle.render(37, 45, 33, ref_camera, objs, seeding=0, math=1, arith=0).pixels[rows])
+    for depth in (1, 2, 7):
+        _exact(both(scene, cam, 9, 16, 4, depth), oracle.render(9, 16, 4, ref_camera, objs, max_depth=depth, seeding=0, math=1).pixels)
+    recs = np.asarray([
+        [0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0],
+        [1, 0, 1, 0, 0, 1.5, 0, 0.0, 1.0, 1.0, 0, .8, .3, .3, 0, 0],
+        [1, -4, 1, 0, -4, 1, 1, 0.25, 0.75, 1.0, 1, .7, .6, .5, 0.3, 0],
+        [1, 4, 1, 0, 5, 1, 0, 0.25, 0.75, 1.0, 2, 0, 0, 0, 0, 1.5],
+        [1, 2, .5, 2, 2, .5, 2, 0.5, 0.5, 0.5, 0, .1, .9, .1, 0, 0],
+        [0, 1, .4, 3, 1, .4, 3, 0, 1, 0.4, 1, .9, .9, .9, 0.0, 0],
+        [0, 1, .4, 3, 1, .4, 3, 0, 1, 0.4, 0, .2, .2, .9, 0.0, 0],
+        [0, -1, .3, 2, -1, .3, 2, 0, 1, -0.3, 2, 0, 0, 0, 0, 1.5],
+    ], dtype=np.float64)
+    edge = tor.Scene.from_records(recs)
+    for (h, w, spp, depth) in ((24, 40, 8, 50), (2, 2, 4, 50), (16, 16, 1, 50)):
+        _exact(both(edge, cam, h, w, spp, depth), oracle.render(h, w, spp, ref_camera, recs, max_depth=depth, seeding=0, math=1).pixels)
+    rng = np.random.default_rng(99)
+    for n in (1300, 2100):
+        big = []
+        for i in range(n):
+            x, z = rng.uniform(-15, 15, 2)
+            if i % 2:
+                big.append([1, x, .2, z, x + rng.uniform(-.3, .3), .2 + rng.uniform(0, .5), z, 0.0, 1.0, .2, i % 3, .6, .5, .4, .2, 1.5])
+            else:
+                big.append([0, x, .2, z, x, .2, z, 0, 1, .2, i % 3, .3, .6, .8, .1, 1.4])
+        big = np.asarray(big, dtype=np.float64)
+        bscene = tor.Scene.from_records(big)
+        got = both(bscene, cam, 12, 20, 3, 10)
+        _exact(got, oracle.render(12, 20, 3, ref_camera, big, max_depth=10, seeding=0, math=1).pixels)
+    # the reference's own main() (C1) through both kernels
+    c1 = both(scene, cam, 216, 384, 100, accel=3)
+    _exact(c1, oracle.render(216, 384, 100, ref_camera, objs, seeding=0, math=1, arith=0).pixels)

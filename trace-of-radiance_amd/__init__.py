@@ -31,6 +31,7 @@ SEED_PIXEL, SEED_SAMPLE = 0, 1
 ARITH_STRICT, ARITH_FUSED = 0, 1
 ACCEL_NONE, ACCEL_BLOCKS, ACCEL_F32 = 0, 1, 2
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
+PIXEL_KERNEL_AUTO, PIXEL_KERNEL_LANE, PIXEL_KERNEL_WAVE = 0, 1, 2
 MAX_DEVICES = 16
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SPHERE, MOVING_SPHERE = 0, 1
@@ -108,7 +109,8 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("seeding", C.c_int32), ("arith", C.c_int32),
                 ("device", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("row_tile", C.c_int32), ("accel", C.c_int32),
-                ("device_count", C.c_int32), ("gather", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES)]
+                ("device_count", C.c_int32), ("gather", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES),
+                ("pixel_kernel", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -415,7 +417,7 @@ def new_canvas(height, width, samples_per_pixel, gamma_correction=2.2) -> Canvas
 
 
 def make_options(seeding=SEED_PIXEL, arith=ARITH_STRICT, device=-1, shard_index=0, shard_count=1,
-                 row_tile=1, accel=0, devices=None, gather=GATHER_AUTO) -> Options:
+                 row_tile=1, accel=0, devices=None, gather=GATHER_AUTO, pixel_kernel=PIXEL_KERNEL_AUTO) -> Options:
     """TorOptions.  devices: a list of HIP ordinals -> tor_render_opt renders row shard k on devices[k] and
     assembles the frame in the canvas (`gather`)."""
     o = Options(C.sizeof(Options), seeding, arith, device, shard_index, shard_count, row_tile, accel)
@@ -424,6 +426,7 @@ def make_options(seeding=SEED_PIXEL, arith=ARITH_STRICT, device=-1, shard_index=
         for k, d in enumerate(devices):
             o.devices[k] = int(d)
     o.gather = gather
+    o.pixel_kernel = pixel_kernel
     return o
 
 

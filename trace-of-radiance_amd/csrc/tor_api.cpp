@@ -79,6 +79,7 @@ hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* c
   cold = (const double*)(b + parts[4].off);
   hot32 = (const float*)(b + parts[5].off);
   n_segs = lay.n_segs;
+  n_sorted = (int)lay.n_sorted;
   has_f32 = false;
   for (int s = 0; s < lay.n_segs; ++s) has_f32 = has_f32 || lay.segs[8 * (size_t)s] >= 5.0;
   return e;
@@ -148,6 +149,7 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
   if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
   if (o.device_count < 0 || o.device_count > TOR_MAX_DEVICES) return false;
   if (o.gather < TOR_GATHER_AUTO || o.gather > TOR_GATHER_HOST) return false;
+  if (o.pixel_kernel < TOR_PIXEL_KERNEL_AUTO || o.pixel_kernel > TOR_PIXEL_KERNEL_WAVE) return false;
   if (o.device_count > 1) {
     if (o.shard_count != 1) return false;  // the device list IS the sharding
     for (int k = 0; k < o.device_count; ++k)
@@ -267,6 +269,7 @@ int tor_context_create(int32_t device, TorContext** out) {
   ctx->num_cus = prop.multiProcessorCount;
   if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
   if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
+  if (const char* c = std::getenv("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
     for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
   e = ctx->counters.ensure(TorContext::kRing * 8 * sizeof(unsigned long long));
@@ -416,6 +419,41 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (o.seeding == TOR_SEED_SAMPLE) HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
 
   tor::KParams p{};
+  // Small SEED_PIXEL frames: one wave per pixel (coop_pixel_kernel) -- the lane-per-pixel kernel would be bound by
+  // the latency of the longest pixel chain.  Same canvas bit for bit; needs only the float64 flat layout.
+  const bool want_wave_kernel = o.pixel_kernel == TOR_PIXEL_KERNEL_WAVE ||
+                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels);
+  if (o.seeding == TOR_SEED_PIXEL && !ctx->collect_stats && want_wave_kernel && ctx->n_objects > 0) {
+    const int rc = tor::ensure_layouts(ctx, 0);
+    if (rc != TOR_OK) return rc;
+    const tor::DeviceLayout& L = ctx->flat[0];
+    p.cold = L.cold;
+    p.n_cold_slots = L.n_sorted;
+    p.coop_slots = (L.n_sorted + 63) / 64 * 64;
+    const int bpc = tor::coop_blocks_per_cu(p, o.arith);
+    if (bpc > 0) {
+      p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
+      p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
+      p.n_pixels = (unsigned)npix;
+      p.work_counter = slot_counters;
+      p.out = d_pixels;
+      ctx->cam_host[slot] = *cam;
+      p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
+      HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, &ctx->cam_host[slot], sizeof(TorCamera), hipMemcpyHostToDevice, stream));
+      long long blocks = (npix + (tor::kThreads / 64) - 1) / (tor::kThreads / 64);
+      const long long resident = (long long)ctx->num_cus * bpc;
+      if (blocks > resident) blocks = resident;
+      HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+      HIP_TRY(tor::launch_coop(p, o.arith, (int)blocks, stream));
+      HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+      ctx->launches += 1;
+      ctx->last_slot = slot;
+      ctx->timing_valid = true;
+      ctx->last_samples = (int64_t)npix * spp;
+      HIP_TRY(tor::launch_finalize(d_pixels, n_values, 1.0 / (double)spp, 1.0 / (double)gamma_correction, stream));
+      return TOR_OK;
+    }
+  }
   {
     const int rc = tor::ensure_layouts(ctx, o.accel);
     if (rc != TOR_OK) return rc;

@@ -70,6 +70,7 @@ struct DeviceLayout {
   const double *stat = nullptr, *mov = nullptr, *movy = nullptr, *segs = nullptr, *cold = nullptr;
   const float* hot32 = nullptr;
   int n_segs = 0;
+  int n_sorted = 0;  // cold slots (padded)
   bool has_f32 = false;
   hipError_t put(const HostLayout& lay, const std::vector<double>* cold_override = nullptr);
   void release() { blob.release(); }
@@ -141,6 +142,9 @@ struct TorContext {
   int max_blocks_per_cu[2][2] = {{2, 3}, {3, 3}};  // [seeding][any TOR_ACCEL_* bit set]
   int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
   int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
+  // SEED_PIXEL frames of at most this many (local) pixels run coop_pixel_kernel (one wave per pixel: the frame is
+  // too small to fill the machine with one lane per pixel chain).  TOR_COOP_MAX_PIXELS overrides; 0 = never.
+  long long coop_max_pixels = 163840;
 };
 
 namespace tor {

@@ -69,11 +69,16 @@ struct KParams {
   unsigned long long* stats;  // nullable: {queries, candidates, wave iterations, samples}
   unsigned long long* wave_log;  // nullable (with stats): per wave {start, end (100 MHz clock), iterations, queries}
   const double* cam_dev;  // 24 float64, TorCamera layout (cameras.nim:15-22)
+  // coop_pixel_kernel (one wave per pixel): number of cold slots of the flat layout and that number padded to 64
+  int n_cold_slots, coop_slots;
 };
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream);
 int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_per_simd);
+size_t coop_lds_bytes(int coop_slots);
+int coop_blocks_per_cu(const KParams& p, int arith);  // 0: the objects do not fit LDS
+hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream);
 int integrate_fixed_lds_bytes(int blocks);  // per workgroup: queues, accumulator cache, debug counters
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
 hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream);
