@@ -529,7 +529,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     int& wg = stage_wg;
     wg = 0;
     auto fits = [&](size_t bytes, int wgs) {
-      return bytes <= hard_cap && bytes + (size_t)tor::integrate_fixed_lds_bytes(1) <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
+      return bytes <= hard_cap && bytes + (size_t)tor::integrate_fixed_lds_bytes(1, p.shot32 != nullptr ? 1 : 0) <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
     };
     for (int tryw = ctx->max_blocks_per_cu[o.seeding][o.accel != 0]; tryw >= 2 && wg == 0; --tryw)
       if (fits(hot_bytes, tryw)) wg = tryw;

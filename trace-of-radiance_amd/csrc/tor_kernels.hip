@@ -114,8 +114,14 @@ static_assert(kBlock == kPad, "hot-record padding must equal the candidate block
 
 // LDS per wave: queue (queue_cap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
 constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 5 section sums, trips, begin, last stamp, 4 statistics, 3 wave-log stamps
-constexpr int wave_lds_bytes(int blocks) { return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8; }
-static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0, "keep LDS carve-outs 16-byte aligned");
+// cooperative resolve (F32 && BLOCKS variants): pair list and survivor list (64 carried over + 512 new per trip), the
+// per-ray closest hit {t bits, tag, f: u64; orig, slot: i32}, two counters
+constexpr int kCoopList = 576;
+constexpr int kCoopBytes = 2 * kCoopList * 4 + 64 * (3 * 8 + 2 * 4) + 16;
+constexpr int wave_lds_bytes(int blocks, int coop = 0) {
+  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? kCoopBytes : 0);
+}
+static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0 && wave_lds_bytes(1, 1) % 16 == 0, "keep LDS carve-outs 16-byte aligned");
 
 // The camera (24 float64) is needed once per new path only; read it there instead of keeping
 // it in 48 SGPRs across the object loop.  The empty asm makes the pointer opaque per call so
@@ -149,12 +155,23 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   constexpr int kQCap = queue_cap(BLOCKS);
-  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS);
+  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS, F32 && BLOCKS);
   unsigned char* wave_lds = smem_raw + wave * kWaveLdsBytes;
   unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
   double* acc_lds = reinterpret_cast<double*>(wave_lds + kQCap * 64 * 4);          // [kAccSlots][3]
   int* tag_lds = reinterpret_cast<int*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 24);  // [kAccSlots]
   unsigned long long* prof_lds = reinterpret_cast<unsigned long long*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 28);
+  // cooperative resolve state (only carved out in the F32 && BLOCKS variants)
+  unsigned char* coop_base = wave_lds + kQCap * 64 * 4 + kAccSlots * 28 + kProfSlots * 8;
+  unsigned long long* coop_t = reinterpret_cast<unsigned long long*>(coop_base);   // [64] closest t so far (bit pattern)
+  unsigned long long* coop_tag = coop_t + 64;                                      // [64] the t coop_orig belongs to
+  double* coop_f = reinterpret_cast<double*>(coop_tag + 64);                       // [64] time fraction of the closest object
+  int* coop_orig = reinterpret_cast<int*>(coop_f + 64);                            // [64] its original index
+  int* coop_slot = coop_orig + 64;                                                 // [64] its cold slot
+  unsigned* coop_pair = reinterpret_cast<unsigned*>(coop_slot + 64);               // [kCoopList] lane | block << 6
+  unsigned* coop_surv = coop_pair + kCoopList;                                     // [kCoopList] lane | cold slot << 6
+  unsigned* coop_cnt = coop_surv + kCoopList;                                      // [0] pairs pending, [1] survivors pending
+  if ((F32 && BLOCKS) && lane == 0) { coop_cnt[0] = 0; coop_cnt[1] = 0; }
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
@@ -337,9 +354,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     if (kProbe && active) path_q += 1;
     bool ended = false;
     V3 radiance = v3(0.0, 0.0, 0.0);
-    if (active) {
+    // kCoop: TOR_ACCEL_BLOCKS | TOR_ACCEL_F32 resolve their candidates COOPERATIVELY (all 64 lanes, active or not,
+    // work through the wave's (ray, block) pairs and (ray, object) survivors: see the resolve section below)
+    constexpr bool kCoop = (F32 != 0) && (BLOCKS != 0);
+    {
       // ================= (B) closest hit over all objects ==============================
       // hittables_lists.nim:48-55 with t_min = 0.001, t_max = Inf (render.nim:28)
+      // (computed by every lane: a lane without a live path works on stale values that nobody reads)
       const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
       const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
       const double a = (ARITH == 0) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
@@ -356,11 +377,27 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       const bool boxes32 = F32 && BLOCKS && p.bnd32 != nullptr;
       if (boxes32) b32 = make_box_ray32(r32, p.sp_bmax);
 
+      // TOR_ACCEL_F32 block expansion: the spatial movers share one time group
+      SegF32 sp32{};
+      if (F32 && BLOCKS && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
+      if (kCoop) {  // this lane's closest hit so far lives in LDS, where the lanes that test its candidates can reach it
+        coop_t[lane] = 0x7ff0000000000000ull;  // +inf
+        coop_tag[lane] = ~0ull;
+        coop_orig[lane] = 0x7fffffff;
+        coop_slot[lane] = -1;
+      }
       int seg = 0;
       int i = 0;
       for (;;) {
         unsigned qn = 0;
         bool full = false;
+        // (seg, i) are the same in every lane that has a live path, but they are updated under `if (active)` inside
+        // this loop, which makes them divergent in the compiler's eyes -- and the object records would then come
+        // through vector loads instead of the scalar data path (measured: half the speed).  readfirstlane inside
+        // the branch restores their uniformity.
+        if (active) {
+        seg = __builtin_amdgcn_readfirstlane(seg);
+        i = __builtin_amdgcn_readfirstlane(i);
         while (seg < p.n_segs) {
           const int seg_kind = (int)segs[seg * 8 + 0];
           const int seg_begin = (int)segs[seg * 8 + 1];    // first hot record of the segment
@@ -541,8 +578,208 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           seg += 1;
           i = 0;
         }
+        }  // if (active)
 
         TOR_SEC(kSecLoop)
+        if constexpr (kCoop) {
+          // ---- cooperative resolve (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) -------------------------------------------
+          // The per-lane version below walks each lane's own boxes: 3.2 block expansions per ray on average but 8
+          // for the worst lane of a wave, ~250 instructions per trip, most lanes idle.  Here the wave pools the
+          // work: (A) every lane turns its queue entries into (ray, block) PAIRS and direct (ray, object) SURVIVORS
+          // in two LDS lists; (B) whenever 64 pairs are pending, the 64 lanes expand one pair each -- the owner's
+          // float32 ray comes over ds_bpermute -- and append the objects the filter keeps to the survivor list;
+          // (C) whenever 64 survivors are pending, the 64 lanes run the reference's float64 test (spheres.nim:28-49)
+          // for one survivor each -- the owner's float64 ray comes over ds_bpermute -- and merge the root into the
+          // owner's closest hit in LDS: atomic min on t, ties to the lowest original index (hittables_lists.nim:48-55).
+          // Every trip of (B)/(C) has 64 busy lanes; lanes whose own path is dead work for the others.
+          const unsigned my_qn = active ? qn : 0u;
+          auto lds_count = [&](unsigned* cnt) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); return (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)cnt); };
+          // (C) one trip: survivors [base, base + n)
+          auto trip_c = [&](unsigned base, unsigned n) {
+            const bool mine = (unsigned)lane < n;
+            const unsigned e = mine ? coop_surv[base + (unsigned)lane] : (unsigned)lane;
+            const int src = (int)(e & 63u);
+            const unsigned slot = e >> 6;
+            const double sox = __shfl(ox, src), soy = __shfl(oy, src), soz = __shfl(oz, src);
+            const double sdx = __shfl(dx, src), sdy = __shfl(dy, src), sdz = __shfl(dz, src);
+            const double sa = __shfl(a, src), stime = __shfl(time, src);
+            bool ok = false;
+            double sol = 0.0, f = 0.0;
+            int orig = 0;
+            if (mine) {
+              const double* c = p.cold + (size_t)slot * 16;
+              double cx = c[0], cy = c[1], cz = c[2];
+              const int flags = (int)__double_as_longlong(c[13]);
+              if (flags & 1) {
+                f = (stime - c[7]) / c[8];
+                if (ARITH == 0) { cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f; }
+                else { cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz); }
+              }
+              const double ocx = sox - cx, ocy = soy - cy, ocz = soz - cz;
+              double hb, cc, disc;
+              if (ARITH == 0) {
+                hb = ocx * sdx + ocy * sdy + ocz * sdz;
+                cc = (ocx * ocx + ocy * ocy + ocz * ocz) - c[15];
+                disc = hb * hb - sa * cc;
+              } else {
+                hb = fma_(ocz, sdz, fma_(ocy, sdy, ocx * sdx));
+                cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -c[15])));
+                disc = fma_(hb, hb, -(sa * cc));
+              }
+              if (disc > 0.0) {  // spheres.nim:35-48
+                const double root = __builtin_sqrt(disc);
+                sol = (-hb - root) / sa;
+                ok = (0.001 < sol) && (sol < __builtin_inf());
+                if (!ok) {
+                  sol = (-hb + root) / sa;
+                  ok = (0.001 < sol) && (sol < __builtin_inf());
+                }
+              }
+              if (ok) orig = (int)__double_as_longlong(c[14]);
+            }
+            // merge into the owner's closest hit.  t > 0, so its bit pattern orders like the value.
+            const unsigned long long sb = (unsigned long long)__double_as_longlong(sol);
+            if (ok) atomicMin(&coop_t[src], sb);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool win = ok && coop_t[src] == sb;
+            // first winner at this t (possibly several lanes, all writing the same values): forget the index that
+            // belonged to a larger t
+            if (win && coop_tag[src] != sb) { coop_tag[src] = sb; coop_orig[src] = 0x7fffffff; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (win) atomicMin(&coop_orig[src], orig);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (win && coop_orig[src] == orig) { coop_slot[src] = (int)slot; coop_f[src] = f; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          };
+          auto drain_c = [&](bool all) {
+            for (;;) {
+              const unsigned cnt = lds_count(&coop_cnt[1]);
+              if (cnt == 0 || (!all && cnt < 64)) break;
+              const unsigned n = cnt < 64 ? cnt : 64;
+              coop_cnt[1] = cnt - n;  // every lane writes the same value
+              if (stats_on) atomicAdd(&prof_lds[kStCand], lane == 0 ? (unsigned long long)n : 0ull);
+              if (prof && lane == 0) prof_lds[kSecTrips] += 1;
+              trip_c(cnt - n, n);
+            }
+          };
+          // (B) one trip: pairs [base, base + n)
+          auto trip_b = [&](unsigned base, unsigned n) {
+            const bool mine = (unsigned)lane < n;
+            const unsigned e = mine ? coop_pair[base + (unsigned)lane] : (unsigned)lane;
+            const int src = (int)(e & 63u);
+            const unsigned blk_id = e >> 6;
+            RayF32 r;
+            r.ox = __shfl(r32.ox, src); r.oy = __shfl(r32.oy, src); r.oz = __shfl(r32.oz, src);
+            r.dx = __shfl(r32.dx, src); r.dy = __shfl(r32.dy, src); r.dz = __shfl(r32.dz, src);
+            r.gma = __shfl(r32.gma, src); r.g = __shfl(r32.g, src);
+            r.ro = 0.f; r.ro2 = 0.f; r.sa = 0.f; r.wild = 0u;
+            SegF32 s;
+            s.nmbl = splat2(__shfl(sp32.nmbl.x, src)); s.gk = splat2(__shfl(sp32.gk.x, src)); s.nf = splat2(__shfl(sp32.nf.x, src));
+            s.wild = (unsigned)__shfl((int)sp32.wild, src);
+            unsigned m8 = 0;
+            if (mine) {
+              auto filter_block = [&](auto blk, auto ST) {
+                constexpr int st = decltype(ST)::value;
+#pragma unroll
+                for (int j = 0; j < kBlock / 2; ++j) {
+                  auto rr = blk + st * j;
+                  const f2v c0x = {rr[0], rr[1]}, c0y = {rr[2], rr[3]}, c0z = {rr[4], rr[5]};
+                  f2v ocx, ocy, ocz;
+                  if (st == 16) {
+                    ocx = oc_moving32(r.ox, c0x, (f2v){rr[10], rr[11]}, s.nf);
+                    ocy = oc_moving32(r.oy, c0y, (f2v){rr[12], rr[13]}, s.nf);
+                    ocz = oc_moving32(r.oz, c0z, (f2v){rr[14], rr[15]}, s.nf);
+                  } else {
+                    ocx = oc_static32(r.ox, c0x);
+                    ocy = (st == 12) ? oc_moving32(r.oy, c0y, (f2v){rr[10], rr[11]}, s.nf) : oc_static32(r.oy, c0y);
+                    ocz = oc_static32(r.oz, c0z);
+                  }
+                  m8 = filter_pair32(r, s, ocx, ocy, ocz, (f2v){rr[6], rr[7]}, (f2v){rr[8], rr[9]}, m8);
+                }
+              };
+              using T10 = std::integral_constant<int, 10>;
+              using T12 = std::integral_constant<int, 12>;
+              using T16 = std::integral_constant<int, 16>;
+              const size_t off = (size_t)blk_id * (size_t)(p.shot32_stride * (kBlock / 2));
+              if (p.shot32_lds_floats > 0) {
+                if (p.shot32_stride == 12) filter_block(shot32_lds + off, T12{});
+                else if (p.shot32_stride == 10) filter_block(shot32_lds + off, T10{});
+                else filter_block(shot32_lds + off, T16{});
+              } else {
+                const gfptr g32 = (gfptr)(uintptr_t)p.shot32;
+                if (p.shot32_stride == 12) filter_block(g32 + off, T12{});
+                else if (p.shot32_stride == 10) filter_block(g32 + off, T10{});
+                else filter_block(g32 + off, T16{});
+              }
+              m8 |= s.wild;
+            }
+            // append the kept objects to the survivor list
+            unsigned at = 0;
+            const unsigned n_keep = (unsigned)__builtin_popcount(m8);
+            if (n_keep != 0) at = atomicAdd(&coop_cnt[1], n_keep);
+            while (m8 != 0) {
+              const int bb = 31 - __builtin_clz(m8);
+              m8 &= ~(1u << bb);
+              coop_surv[at++] = (unsigned)src | (((unsigned)p.spatial_base + blk_id * kBlock + (unsigned)(7 - bb)) << 6);
+            }
+          };
+          auto drain_b = [&](bool all) {
+            for (;;) {
+              const unsigned cnt = lds_count(&coop_cnt[0]);
+              if (cnt == 0 || (!all && cnt < 64)) break;
+              const unsigned n = cnt < 64 ? cnt : 64;
+              coop_cnt[0] = cnt - n;
+              if (stats_on) atomicAdd(&prof_lds[kStCand], lane == 0 ? (unsigned long long)n * kBlock : 0ull);
+              if (prof && lane == 0) prof_lds[kSecTrips] += 1;
+              trip_b(cnt - n, n);
+              drain_c(false);
+            }
+          };
+          // (A) queue entries -> pairs / direct survivors.  One 'unit' per lane and trip: a whole entry of object
+          // bits or block-box bits, or ONE bit of a super-box entry (its 8 child boxes are slab-tested here) --
+          // at most 8 list entries per lane and trip, so the lists (64 carried over + 512) cannot overflow.
+          unsigned kq = 0, sup_mask = 0, sup_block = 0;
+          for (;;) {
+            unsigned kind = 3, m = 0, blk = 0;  // 3: nothing this trip
+            if (sup_mask != 0) {
+              const int b = 31 - __builtin_clz(sup_mask);
+              sup_mask &= ~(1u << b);
+              const unsigned rec = sup_block * kBlock + (unsigned)(7 - b);  // super box `rec`: its block boxes are rec*8 .. rec*8+7
+              unsigned mc = 0;
+              auto child32 = [&](auto cb) {
+#pragma unroll 4
+                for (int j = 0; j < kBlock; ++j)
+                  mc = (mc << 1) | slab_bit32(b32, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
+                                              (f2v){cb[8 * j + 4], cb[8 * j + 5]});
+              };
+              if (p.bnd32_lds_floats > 0) child32(bnd32_lds + (size_t)rec * (8 * kBlock));
+              else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
+              mc |= r32.wild;
+              kind = 2; m = mc; blk = rec;
+            } else if (kq < my_qn) {
+              const unsigned e = q[kq * 64];
+              kq += 1;
+              const unsigned k3 = e >> 30;  // 0: object mask, 2: block boxes, 1: super boxes
+              if (k3 == 1) { sup_mask = e & 0xffu; sup_block = (e >> 8) & 0x3fffffu; kind = 4; }  // expanded bit by bit from the next trip on
+              else { kind = k3; m = e & 0xffu; blk = (e >> 8) & 0x3fffffu; }
+            }
+            if (ballot64(kind != 3) == 0) break;
+            const unsigned n_new = (kind == 0 || kind == 2) ? (unsigned)__builtin_popcount(m) : 0u;
+            unsigned at = 0;
+            if (n_new != 0) at = atomicAdd(&coop_cnt[kind == 2 ? 0 : 1], n_new);
+            while (n_new != 0 && m != 0) {
+              const int b = 31 - __builtin_clz(m);
+              m &= ~(1u << b);
+              const unsigned id = blk * kBlock + (unsigned)(7 - b);  // block id, or cold slot of a direct candidate
+              if (kind == 2) coop_pair[at++] = (unsigned)lane | (id << 6);
+              else coop_surv[at++] = (unsigned)lane | (id << 6);
+            }
+            drain_b(false);
+            drain_c(false);
+          }
+          drain_b(true);
+          drain_c(true);
+        } else if (active) {
         // ---- resolve the queued candidates exactly as spheres.nim:35-48 does -------------
         // Queue entries are 8-bit masks over 8 consecutive cold slots (direct candidates) or, flagged
         // with bit 31, over 8 block bounds.  A trip of the loop handles one set bit per lane: either
@@ -617,9 +854,6 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
           exact_hit(cx, cy, cz, c[15], slot, f);
         };
-        // TOR_ACCEL_F32 block expansion: the spatial movers share one time group
-        SegF32 sp32{};
-        if (F32 && BLOCKS && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
         unsigned kq = 0, cur_mask = 0, cur_block = 0, cur_is_bound = 0;
         for (;;) {
           if (cur_mask == 0 && kq < qn) {
@@ -760,9 +994,17 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             }
           }
         }
+        }  // per-lane resolve
         TOR_SEC(kSecResolve)
-        if (!full) break;
+        if (ballot64(active && full) == 0) break;
       }
+      if (kCoop) {  // the closest hit the wave found for this lane's ray
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        best_idx = coop_slot[lane];
+        best_t = __longlong_as_double((long long)coop_t[lane]);
+        best_f = coop_f[lane];
+      }
+      if (active) {
 
       // ================= (C) shade ====================================================
       if (best_idx < 0) {
@@ -841,6 +1083,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
         }
       }
+      }  // if (active)
     }
 
     TOR_SEC(kSecShade)
@@ -1287,7 +1530,7 @@ static int clamp_w(int waves_per_simd) {
 static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? 1 : 0; }
 static size_t dynamic_lds(const KParams& p) {
-  return (size_t)wave_lds_bytes(wants_blocks(p)) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
+  return (size_t)wave_lds_bytes(wants_blocks(p), wants_blocks(p) && wants_f32(p)) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
          (size_t)p.bnd32_lds_floats * 4;
 }
 
@@ -1339,7 +1582,7 @@ hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stre
   return hipGetLastError();
 }
 
-int integrate_fixed_lds_bytes(int blocks) { return wave_lds_bytes(blocks) * (kThreads / 64); }
+int integrate_fixed_lds_bytes(int blocks, int coop) { return wave_lds_bytes(blocks, coop) * (kThreads / 64); }
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {
   if (n_values <= 0) return hipSuccess;

@@ -79,7 +79,7 @@ int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_
 size_t coop_lds_bytes(int coop_slots);
 int coop_blocks_per_cu(const KParams& p, int arith);  // 0: the objects do not fit LDS
 hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream);
-int integrate_fixed_lds_bytes(int blocks);  // per workgroup: queues, accumulator cache, debug counters
+int integrate_fixed_lds_bytes(int blocks, int coop);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists)
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
 hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream);
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
