@@ -115,9 +115,9 @@ static_assert(kBlock == kPad, "hot-record padding must equal the candidate block
 // LDS per wave: queue (queue_cap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
 constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 5 section sums, trips, begin, last stamp, 4 statistics, 3 wave-log stamps
 // cooperative resolve (F32 && BLOCKS variants): pair list and survivor list (64 carried over + 512 new per trip), the
-// per-ray closest hit {t bits, tag, f: u64; orig, slot: i32}, two counters
+// per-ray closest hit {t bits, (original index, slot)}
 constexpr int kCoopList = 576;
-constexpr int kCoopBytes = 2 * kCoopList * 4 + 64 * (3 * 8 + 2 * 4) + 16;
+constexpr int kCoopBytes = 2 * kCoopList * 4 + 64 * 2 * 8;
 constexpr int wave_lds_bytes(int blocks, int coop = 0) {
   return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? kCoopBytes : 0);
 }
@@ -144,6 +144,21 @@ __device__ __forceinline__ Camera load_camera(const double* cam_dev) {
   return cam;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave and the wave total: DPP row shifts inside rows of 16 lanes, the
+// three row totals through scalar registers.
+__device__ __forceinline__ void wave_scan_u32(unsigned v, unsigned& incl, unsigned& total) {
+  // __builtin_amdgcn_update_dpp(old, src, dpp_ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source get `old`
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+  const unsigned row = (unsigned)(threadIdx.x & 63) >> 4;
+  incl = v + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
+  total = r0 + r1 + r2 + r3;
+}
+
 // m = (m << 1) | (t >> 31) in one v_alignbit_b32
 __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
   return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
@@ -164,14 +179,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   // cooperative resolve state (only carved out in the F32 && BLOCKS variants)
   unsigned char* coop_base = wave_lds + kQCap * 64 * 4 + kAccSlots * 28 + kProfSlots * 8;
   unsigned long long* coop_t = reinterpret_cast<unsigned long long*>(coop_base);   // [64] closest t so far (bit pattern)
-  unsigned long long* coop_tag = coop_t + 64;                                      // [64] the t coop_orig belongs to
-  double* coop_f = reinterpret_cast<double*>(coop_tag + 64);                       // [64] time fraction of the closest object
-  int* coop_orig = reinterpret_cast<int*>(coop_f + 64);                            // [64] its original index
-  int* coop_slot = coop_orig + 64;                                                 // [64] its cold slot
-  unsigned* coop_pair = reinterpret_cast<unsigned*>(coop_slot + 64);               // [kCoopList] lane | block << 6
+  unsigned long long* coop_w = coop_t + 64;                                        // [64] (original index << 32) | cold slot at that t
+  unsigned* coop_pair = reinterpret_cast<unsigned*>(coop_w + 64);                  // [kCoopList] lane | block << 6
   unsigned* coop_surv = coop_pair + kCoopList;                                     // [kCoopList] lane | cold slot << 6
-  unsigned* coop_cnt = coop_surv + kCoopList;                                      // [0] pairs pending, [1] survivors pending
-  if ((F32 && BLOCKS) && lane == 0) { coop_cnt[0] = 0; coop_cnt[1] = 0; }
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
@@ -382,10 +392,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       if (F32 && BLOCKS && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
       if (kCoop) {  // this lane's closest hit so far lives in LDS, where the lanes that test its candidates can reach it
         coop_t[lane] = 0x7ff0000000000000ull;  // +inf
-        coop_tag[lane] = ~0ull;
-        coop_orig[lane] = 0x7fffffff;
-        coop_slot[lane] = -1;
+        coop_w[lane] = ~0ull;                  // (original index << 32) | cold slot of the object at that t
       }
+      // kCoop: the slab tests of a box segment of at most 64 boxes leave their bits in a register pair (bit 63 - k <->
+      // box k) instead of the LDS queue
+      unsigned long long box_mask = 0;
+      int box_kind = 0;       // 3: block boxes, 4: super boxes
+      unsigned box_group0 = 0;  // index of the first group of 8 boxes (first box / 8)
       int seg = 0;
       int i = 0;
       for (;;) {
@@ -483,6 +496,25 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           } else if (F32 && BLOCKS && (seg_kind == 3 || seg_kind == 4)) {
             // the same boxes through the float32 slab test (tor_filter32.hpp): 8 floats per record via scalar loads
             cfptr rec = (cfptr)(uintptr_t)p.bnd32 + 8 * (long)(seg_begin + i);
+            if (kCoop && seg_count <= 64) {
+              box_kind = seg_kind;
+              box_group0 = (unsigned)seg_block0;
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < kBlock; ++j)
+                  m = (m << 1) | slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
+                                            (f2v){rec[8 * j + 4], rec[8 * j + 5]});
+                rec += 8 * kBlock;
+                unsigned wild = r32.wild;  // (see below: never into the padding super boxes)
+                if (seg_kind == 4) {
+                  const int n_valid = p.n_super - i;
+                  wild &= (n_valid >= kBlock) ? 0xffu : ((n_valid <= 0) ? 0u : ((0xff00u >> n_valid) & 0xffu));
+                }
+                m |= wild;
+                box_mask |= (unsigned long long)m << (56 - i);
+              }
+            } else
             for (; i < seg_count; i += kBlock) {
               unsigned m = 0;
 #pragma unroll
@@ -586,14 +618,15 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           // The per-lane version below walks each lane's own boxes: 3.2 block expansions per ray on average but 8
           // for the worst lane of a wave, ~250 instructions per trip, most lanes idle.  Here the wave pools the
           // work: (A) every lane turns its queue entries into (ray, block) PAIRS and direct (ray, object) SURVIVORS
-          // in two LDS lists; (B) whenever 64 pairs are pending, the 64 lanes expand one pair each -- the owner's
-          // float32 ray comes over ds_bpermute -- and append the objects the filter keeps to the survivor list;
-          // (C) whenever 64 survivors are pending, the 64 lanes run the reference's float64 test (spheres.nim:28-49)
-          // for one survivor each -- the owner's float64 ray comes over ds_bpermute -- and merge the root into the
-          // owner's closest hit in LDS: atomic min on t, ties to the lowest original index (hittables_lists.nim:48-55).
+          // in two LDS lists (positions from a DPP prefix sum, the counts stay in scalar registers); (B) whenever
+          // 64 pairs are pending, the 64 lanes expand one pair each -- the owner's float32 ray comes over
+          // ds_bpermute -- and append the objects the filter keeps to the survivor list; (C) whenever 64 survivors
+          // are pending, the 64 lanes run the reference's float64 test (spheres.nim:28-49) for one survivor each --
+          // the owner's float64 ray comes over ds_bpermute -- and merge the root into the owner's closest hit in
+          // LDS: atomic min on t, ties to the lowest original index (hittables_lists.nim:48-55).
           // Every trip of (B)/(C) has 64 busy lanes; lanes whose own path is dead work for the others.
           const unsigned my_qn = active ? qn : 0u;
-          auto lds_count = [&](unsigned* cnt) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); return (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)cnt); };
+          unsigned n_pairs = 0, n_surv = 0;  // pending list entries (wave-uniform)
           // (C) one trip: survivors [base, base + n)
           auto trip_c = [&](unsigned base, unsigned n) {
             const bool mine = (unsigned)lane < n;
@@ -604,14 +637,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             const double sdx = __shfl(dx, src), sdy = __shfl(dy, src), sdz = __shfl(dz, src);
             const double sa = __shfl(a, src), stime = __shfl(time, src);
             bool ok = false;
-            double sol = 0.0, f = 0.0;
+            double sol = 0.0;
             int orig = 0;
             if (mine) {
               const double* c = p.cold + (size_t)slot * 16;
               double cx = c[0], cy = c[1], cz = c[2];
               const int flags = (int)__double_as_longlong(c[13]);
               if (flags & 1) {
-                f = (stime - c[7]) / c[8];
+                const double f = (stime - c[7]) / c[8];
                 if (ARITH == 0) { cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f; }
                 else { cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz); }
               }
@@ -637,30 +670,35 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               }
               if (ok) orig = (int)__double_as_longlong(c[14]);
             }
-            // merge into the owner's closest hit.  t > 0, so its bit pattern orders like the value.
+            // Merge into the owner's closest hit {t, (original index, slot)}.  t > 0, so its bit pattern orders like
+            // the value.  A lane that LOWERS t knows the (index, slot) word belongs to a larger t and resets it;
+            // then every lane whose root equals the owner's t (ties: duplicate objects) competes with its
+            // (index << 32 | slot), the lowest original index wins.
             const unsigned long long sb = (unsigned long long)__double_as_longlong(sol);
-            if (ok) atomicMin(&coop_t[src], sb);
+            unsigned long long old_t = 0;
+            if (ok) old_t = atomicMin(&coop_t[src], sb);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const bool win = ok && coop_t[src] == sb;
-            // first winner at this t (possibly several lanes, all writing the same values): forget the index that
-            // belonged to a larger t
-            if (win && coop_tag[src] != sb) { coop_tag[src] = sb; coop_orig[src] = 0x7fffffff; }
+            if (win && old_t > sb) coop_w[src] = ~0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (win) atomicMin(&coop_orig[src], orig);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (win && coop_orig[src] == orig) { coop_slot[src] = (int)slot; coop_f[src] = f; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (win) atomicMin(&coop_w[src], ((unsigned long long)(unsigned)orig << 32) | (unsigned long long)slot);
           };
           auto drain_c = [&](bool all) {
-            for (;;) {
-              const unsigned cnt = lds_count(&coop_cnt[1]);
-              if (cnt == 0 || (!all && cnt < 64)) break;
-              const unsigned n = cnt < 64 ? cnt : 64;
-              coop_cnt[1] = cnt - n;  // every lane writes the same value
+            while (n_surv != 0 && (all || n_surv >= 64)) {
+              const unsigned n = n_surv < 64 ? n_surv : 64;
+              n_surv -= n;
               if (stats_on) atomicAdd(&prof_lds[kStCand], lane == 0 ? (unsigned long long)n : 0ull);
               if (prof && lane == 0) prof_lds[kSecTrips] += 1;
-              trip_c(cnt - n, n);
+              trip_c(n_surv, n);
             }
+          };
+          // appends cnt entries per lane (cnt <= 8) to a list: returns this lane's first position, bumps the count
+          auto reserve = [&](unsigned cnt, unsigned& total) {
+            unsigned incl, sum;
+            wave_scan_u32(cnt, incl, sum);
+            const unsigned at = total + incl - cnt;
+            total += sum;
+            return at;
           };
           // (B) one trip: pairs [base, base + n)
           auto trip_b = [&](unsigned base, unsigned n) {
@@ -714,31 +752,75 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               m8 |= s.wild;
             }
             // append the kept objects to the survivor list
-            unsigned at = 0;
-            const unsigned n_keep = (unsigned)__builtin_popcount(m8);
-            if (n_keep != 0) at = atomicAdd(&coop_cnt[1], n_keep);
+            unsigned at = reserve((unsigned)__builtin_popcount(m8), n_surv);
             while (m8 != 0) {
               const int bb = 31 - __builtin_clz(m8);
               m8 &= ~(1u << bb);
               coop_surv[at++] = (unsigned)src | (((unsigned)p.spatial_base + blk_id * kBlock + (unsigned)(7 - bb)) << 6);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           };
           auto drain_b = [&](bool all) {
-            for (;;) {
-              const unsigned cnt = lds_count(&coop_cnt[0]);
-              if (cnt == 0 || (!all && cnt < 64)) break;
-              const unsigned n = cnt < 64 ? cnt : 64;
-              coop_cnt[0] = cnt - n;
+            while (n_pairs != 0 && (all || n_pairs >= 64)) {
+              const unsigned n = n_pairs < 64 ? n_pairs : 64;
+              n_pairs -= n;
               if (stats_on) atomicAdd(&prof_lds[kStCand], lane == 0 ? (unsigned long long)n * kBlock : 0ull);
               if (prof && lane == 0) prof_lds[kSecTrips] += 1;
-              trip_b(cnt - n, n);
+              trip_b(n_pairs, n);
               drain_c(false);
             }
           };
           // (A) queue entries -> pairs / direct survivors.  One 'unit' per lane and trip: a whole entry of object
           // bits or block-box bits, or ONE bit of a super-box entry (its 8 child boxes are slab-tested here) --
-          // at most 8 list entries per lane and trip, so the lists (64 carried over + 512) cannot overflow.
+          // at most 8 list entries per lane and trip, so the lists (< 64 carried over + 512) cannot overflow.
           unsigned kq = 0, sup_mask = 0, sup_block = 0;
+          {
+            // Fast path (no super-box entries in the wave, everything fits the lists): count the bits of all
+            // entries, ONE prefix sum for both lists (the two counts share a word), then write.
+            if (!active) box_mask = 0;
+            bool has_super = box_kind == 4 && box_mask != 0;
+            unsigned cnt2 = has_super ? 0u : (unsigned)__builtin_popcountll(box_mask);  // pairs | direct survivors << 16
+            for (unsigned k = 0; k < my_qn; ++k) {
+              const unsigned e = q[k * 64];
+              const unsigned k3 = e >> 30;
+              const unsigned bits = (unsigned)__builtin_popcount(e & 0xffu);
+              cnt2 += (k3 == 2) ? bits : ((k3 == 0) ? (bits << 16) : 0u);
+              has_super = has_super || (k3 == 1);
+            }
+            unsigned incl, total;
+            wave_scan_u32(cnt2, incl, total);
+            const unsigned tot_p = total & 0xffffu, tot_s = total >> 16;
+            if (ballot64(has_super) == 0 && n_pairs + tot_p <= (unsigned)kCoopList && n_surv + tot_s <= (unsigned)kCoopList) {
+              unsigned at_p = n_pairs + (incl & 0xffffu) - (cnt2 & 0xffffu);
+              unsigned at_s = n_surv + (incl >> 16) - (cnt2 >> 16);
+              n_pairs += tot_p;
+              n_surv += tot_s;
+              while (box_mask != 0) {
+                const int b = __builtin_clzll(box_mask);  // box b of the segment
+                box_mask &= ~(0x8000000000000000ull >> b);
+                coop_pair[at_p++] = (unsigned)lane | ((box_group0 * kBlock + (unsigned)b) << 6);
+              }
+              for (; kq < my_qn; ++kq) {
+                const unsigned e = q[kq * 64];
+                const unsigned blk = (e >> 8) & 0x3fffffu;
+                unsigned m = e & 0xffu;
+                if ((e >> 30) == 2) {
+                  while (m != 0) {
+                    const int b = 31 - __builtin_clz(m);
+                    m &= ~(1u << b);
+                    coop_pair[at_p++] = (unsigned)lane | ((blk * kBlock + (unsigned)(7 - b)) << 6);
+                  }
+                } else {
+                  while (m != 0) {
+                    const int b = 31 - __builtin_clz(m);
+                    m &= ~(1u << b);
+                    coop_surv[at_s++] = (unsigned)lane | ((blk * kBlock + (unsigned)(7 - b)) << 6);
+                  }
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+          }
           for (;;) {
             unsigned kind = 3, m = 0, blk = 0;  // 3: nothing this trip
             if (sup_mask != 0) {
@@ -756,6 +838,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
               mc |= r32.wild;
               kind = 2; m = mc; blk = rec;
+            } else if (box_mask != 0) {
+              const int g = __builtin_clzll(box_mask) >> 3;  // group of 8 boxes
+              const unsigned mm = (unsigned)(box_mask >> (56 - 8 * g)) & 0xffu;
+              box_mask &= ~(0xffull << (56 - 8 * g));
+              if (box_kind == 4) { sup_mask = mm; sup_block = box_group0 + (unsigned)g; kind = 4; }
+              else { kind = 2; m = mm; blk = box_group0 + (unsigned)g; }
             } else if (kq < my_qn) {
               const unsigned e = q[kq * 64];
               kq += 1;
@@ -764,16 +852,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               else { kind = k3; m = e & 0xffu; blk = (e >> 8) & 0x3fffffu; }
             }
             if (ballot64(kind != 3) == 0) break;
-            const unsigned n_new = (kind == 0 || kind == 2) ? (unsigned)__builtin_popcount(m) : 0u;
-            unsigned at = 0;
-            if (n_new != 0) at = atomicAdd(&coop_cnt[kind == 2 ? 0 : 1], n_new);
-            while (n_new != 0 && m != 0) {
+            const unsigned n_bits = (unsigned)__builtin_popcount(m);
+            unsigned at_p = reserve(kind == 2 ? n_bits : 0u, n_pairs);
+            unsigned at_s = reserve(kind == 0 ? n_bits : 0u, n_surv);
+            if (kind != 0 && kind != 2) m = 0;
+            while (m != 0) {
               const int b = 31 - __builtin_clz(m);
               m &= ~(1u << b);
               const unsigned id = blk * kBlock + (unsigned)(7 - b);  // block id, or cold slot of a direct candidate
-              if (kind == 2) coop_pair[at++] = (unsigned)lane | (id << 6);
-              else coop_surv[at++] = (unsigned)lane | (id << 6);
+              if (kind == 2) coop_pair[at_p++] = (unsigned)lane | (id << 6);
+              else coop_surv[at_s++] = (unsigned)lane | (id << 6);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             drain_b(false);
             drain_c(false);
           }
@@ -1000,9 +1090,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       }
       if (kCoop) {  // the closest hit the wave found for this lane's ray
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        best_idx = coop_slot[lane];
         best_t = __longlong_as_double((long long)coop_t[lane]);
-        best_f = coop_f[lane];
+        best_idx = (best_t < __builtin_inf()) ? (int)(unsigned)coop_w[lane] : -1;
+        if (best_idx >= 0) {  // the time fraction of a moving object, as moving_spheres.nim:42 computes it
+          const double* c = p.cold + (size_t)best_idx * 16;
+          if ((int)__double_as_longlong(c[13]) & 1) best_f = (time - c[7]) / c[8];
+        }
       }
       if (active) {
 
