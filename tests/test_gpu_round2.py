@@ -210,24 +210,24 @@ def test_scene_cache_and_host_canvas_region(tor):
     assert ctx.scene_counters() == (1, 0, 0)          # nothing built yet
     buf = torch.empty((27, 48, 3), dtype=torch.float64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(), buf.data_ptr(), s)
+    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE), buf.data_ptr(), s)
     torch.cuda.synchronize()
     assert ctx.scene_counters() == (1, 0, 1)          # only the float64 flat layout
     ctx.upload(scene.list())
     ctx.upload(tor.random_scene(0xFACADE).list())     # another buffer, same bytes
     assert ctx.scene_counters() == (3, 2, 1)
     base = buf.clone()
-    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(accel=3), buf.data_ptr(), s)
+    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE, accel=3), buf.data_ptr(), s)
     torch.cuda.synchronize()
     assert torch.equal(buf, base) and ctx.scene_counters()[2] == 2
     other = tor.random_scene(0xBEEF)
     ctx.upload(other.list())
     assert ctx.scene_counters()[1] == 2
-    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(accel=3), buf.data_ptr(), s)
+    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE, accel=3), buf.data_ptr(), s)
     torch.cuda.synchronize()
     assert not torch.equal(buf, base)
     ctx.upload(scene.list())
-    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(accel=1), buf.data_ptr(), s)
+    ctx.render_device(cam, 27, 48, 4, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE, accel=1), buf.data_ptr(), s)
     torch.cuda.synchronize()
     assert torch.equal(buf, base)
     ctx.close()

@@ -159,9 +159,18 @@ TOR_HD double schlick(double cosine, double ri) {
   return r0 + (1.0 - r0) * pow5(1.0 - cosine);
 }
 
+// schlick() with r0 = ((1 - eta)/(1 + eta))^2 taken from the object's record (the host evaluates exactly these
+// operations once per object and side: tor_scene.cpp fill_material)
+TOR_HD double schlick_r0(double cosine, double r0) { return r0 + (1.0 - r0) * pow5(1.0 - cosine); }
+
 enum : int { kLambertian = 0, kMetal = 1, kDielectric = 2 };  // core.nim:25-27
 
 // render.nim:41-45: the sky gradient on a miss (note `0.5*y + 1.0`, as the reference has it)
+TOR_HD V3 sky_unit(V3 ud, V3 att) {  // ud = unit_vector(direction), computed by the caller
+  double t = 0.5 * ud.y + 1.0;
+  V3 res = v3(1.0, 1.0, 1.0) * (1.0 - t) + v3(0.5, 0.7, 1.0) * t;
+  return mul_att(res, att);
+}
 TOR_HD V3 sky(V3 direction, V3 att) {
   V3 ud = unit_vector(direction);
   double t = 0.5 * ud.y + 1.0;

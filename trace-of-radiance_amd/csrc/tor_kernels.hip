@@ -389,7 +389,11 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
       // TOR_ACCEL_F32 block expansion: the spatial movers share one time group
       SegF32 sp32{};
-      if (F32 && BLOCKS && p.shot32 != nullptr) sp32 = make_seg_f32(r32, (time - p.sp_t0) / p.sp_dt, p.sp_mc0max, p.sp_dcmax);
+      double f_sp = 0.0;  // moving_spheres.nim:42 for the spatial movers' (time0, time1)
+      if (F32 && BLOCKS && p.shot32 != nullptr) {
+        f_sp = (time - p.sp_t0) / p.sp_dt;
+        sp32 = make_seg_f32(r32, f_sp, p.sp_mc0max, p.sp_dcmax);
+      }
       if (kCoop) {  // this lane's closest hit so far lives in LDS, where the lanes that test its candidates can reach it
         coop_t[lane] = 0x7ff0000000000000ull;  // +inf
         coop_w[lane] = ~0ull;                  // (original index << 32) | cold slot of the object at that t
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             const unsigned slot = e >> 6;
             const double sox = __shfl(ox, src), soy = __shfl(oy, src), soz = __shfl(oz, src);
             const double sdx = __shfl(dx, src), sdy = __shfl(dy, src), sdz = __shfl(dz, src);
-            const double sa = __shfl(a, src), stime = __shfl(time, src);
+            const double sa = __shfl(a, src), stime = __shfl(time, src), sfsp = __shfl(f_sp, src);
             bool ok = false;
             double sol = 0.0;
             int orig = 0;
@@ -644,7 +648,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               double cx = c[0], cy = c[1], cz = c[2];
               const int flags = (int)__double_as_longlong(c[13]);
               if (flags & 1) {
-                const double f = (stime - c[7]) / c[8];
+                // the owner already divided for the spatial movers' time group: same operands, same quotient
+                const double f = (c[7] == p.sp_t0 && c[8] == p.sp_dt) ? sfsp : (stime - c[7]) / c[8];
                 if (ARITH == 0) { cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f; }
                 else { cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz); }
               }
@@ -1094,14 +1099,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         best_idx = (best_t < __builtin_inf()) ? (int)(unsigned)coop_w[lane] : -1;
         if (best_idx >= 0) {  // the time fraction of a moving object, as moving_spheres.nim:42 computes it
           const double* c = p.cold + (size_t)best_idx * 16;
-          if ((int)__double_as_longlong(c[13]) & 1) best_f = (time - c[7]) / c[8];
+          if ((int)__double_as_longlong(c[13]) & 1) best_f = (c[7] == p.sp_t0 && c[8] == p.sp_dt) ? f_sp : (time - c[7]) / c[8];
         }
       }
       if (active) {
 
       // ================= (C) shade ====================================================
+      // unit_vector(direction) is needed by the sky (render.nim:42), Metal (materials.nim:40) and Dielectric
+      // (materials.nim:68): the wave would walk through three copies of the square root and the division -- one
+      // copy, in front of the branches, serves all of them (same operations on the same ray: same bits)
+      const V3 ud_ray = unit_vector(d);
       if (best_idx < 0) {
-        radiance = sky(d, att);  // render.nim:41-45
+        radiance = sky_unit(ud_ray, att);  // render.nim:41-45
         ended = true;
       } else {
         const double* c = p.cold + (size_t)best_idx * 16;
@@ -1122,7 +1131,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           o = hp;
           att = mul_att(att, albedo);  // render.nim:35
         } else if (mat == kMetal) {  // materials.nim:39-47
-          const V3 reflected = reflect(unit_vector(d), n);
+          const V3 reflected = reflect(ud_ray, n);
           const V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
           o = hp;
           d = nd;
@@ -1133,9 +1142,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             ended = true;  // render.nim:38: absorbed -> black
           }
         } else {  // materials.nim:62-86
-          const double ri = c[12];
-          const double eta = front ? 1.0 / ri : ri;
-          const V3 ud = unit_vector(d);
+          const double eta = front ? c[9] : c[12];  // 1.0 / ri : ri  (the quotient comes from the host, tor_scene.cpp)
+          const V3 ud = ud_ray;
           const double dn = dot(-ud, n);
           const double cos_theta = (dn <= 1.0) ? dn : 1.0;
           const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
@@ -1143,7 +1151,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           if (eta * sin_theta > 1.0) {
             nd = reflect(ud, n);
           } else {
-            const double reflect_prob = schlick(cos_theta, eta);
+            const double reflect_prob = schlick_r0(cos_theta, front ? c[10] : c[11]);
             if (uniform01(rng) < reflect_prob) nd = reflect(ud, n);
             else nd = refract(ud, n, eta);
           }
@@ -1440,8 +1448,7 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
           if (dot(nd, n) > 0.0) att = mul_att(att, albedo);
           else absorbed = true;
         } else {  // materials.nim:62-86
-          const double ri = c[12];
-          const double eta = front ? 1.0 / ri : ri;
+          const double eta = front ? c[9] : c[12];  // 1.0 / ri : ri
           const V3 ud = unit_vector(d);
           const double dn = dot(-ud, n);
           const double cos_theta = (dn <= 1.0) ? dn : 1.0;
@@ -1450,7 +1457,7 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
           if (eta * sin_theta > 1.0) {
             nd = reflect(ud, n);
           } else {
-            const double reflect_prob = schlick(cos_theta, eta);
+            const double reflect_prob = schlick_r0(cos_theta, front ? c[10] : c[11]);
             if (uniform01(rng) < reflect_prob) nd = reflect(ud, n);
             else nd = refract(ud, n, eta);
           }

@@ -34,9 +34,20 @@ bool fill_material(double* c, const TorMaterial& m, int moving) {
       c[9] = m.u.metal.albedo.x; c[10] = m.u.metal.albedo.y; c[11] = m.u.metal.albedo.z;
       c[12] = m.u.metal.fuzz;
       return true;
-    case TOR_DIELECTRIC:
-      c[12] = m.u.dielectric.refraction_index;
+    case TOR_DIELECTRIC: {
+      const double ri = m.u.dielectric.refraction_index;
+      c[12] = ri;
+      // per-object constants of Dielectric.scatter, evaluated here with the reference's own operations
+      // (materials.nim:55-60,66: `1.0 / ri`, r0 = (1 - eta)/(1 + eta), r0 * r0); the albedo slots are free
+      // (materials.nim:64: attenuation = (1, 1, 1))
+      const double inv = 1.0 / ri;
+      double r0f = (1.0 - inv) / (1.0 + inv);
+      double r0b = (1.0 - ri) / (1.0 + ri);
+      c[9] = inv;
+      c[10] = r0f * r0f;   // front face: eta = 1/ri
+      c[11] = r0b * r0b;   // back face:  eta = ri
       return true;
+    }
     default:
       return false;
   }
