@@ -565,9 +565,11 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   } else {
     p.total_work = (unsigned long long)npix * (unsigned long long)spp;
     long long c = (long long)(p.total_work / (unsigned long long)(resident_waves * 16));
+    // largest chunk of the guided schedule: up to 1024 samples, or one whole pixel when a pixel has more (<= 4096)
+    const long long cap_c = (spp > 1024) ? (spp < 4096 ? spp : 4096) : 1024;
     if (c < 64) c = 64;
-    if (c > 1024) c = 1024;
-    p.chunk = (unsigned)(c / 64 * 64);
+    if (c > cap_c) c = cap_c;
+    p.chunk = (unsigned)((c >= spp) ? c : c / 64 * 64);
     waves = (long long)((p.total_work + 63) / 64);
   }
   if (waves > resident_waves) waves = resident_waves;
