@@ -117,11 +117,14 @@ constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 
 // cooperative resolve (F32 && BLOCKS variants): pair list and survivor list (64 carried over + 512 new per trip), the
 // per-ray closest hit {t bits, (original index, slot)}
 constexpr int kCoopList = 576;
-constexpr int kCoopBytes = 2 * kCoopList * 4 + 64 * 2 * 8;
+constexpr int coop_bytes(int blocks) { return (blocks ? 2 : 1) * kCoopList * 4 + 64 * 2 * 8; }  // (no pair list without boxes)
 constexpr int wave_lds_bytes(int blocks, int coop = 0) {
-  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? kCoopBytes : 0);
+  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) : 0);
 }
-static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0 && wave_lds_bytes(1, 1) % 16 == 0, "keep LDS carve-outs 16-byte aligned");
+// which kernel variants resolve cooperatively: every one except block culling with float64 expansion (F32 = 0, BLOCKS = 1)
+constexpr bool coop_variant(int f32, int blocks) { return blocks == 0 || f32 != 0; }
+static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0 && wave_lds_bytes(1, 1) % 16 == 0 && wave_lds_bytes(0, 1) % 16 == 0,
+              "keep LDS carve-outs 16-byte aligned");
 
 // The camera (24 float64) is needed once per new path only; read it there instead of keeping
 // it in 48 SGPRs across the object loop.  The empty asm makes the pointer opaque per call so
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   constexpr int kQCap = queue_cap(BLOCKS);
-  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS, F32 && BLOCKS);
+  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS, coop_variant(F32, BLOCKS));
   unsigned char* wave_lds = smem_raw + wave * kWaveLdsBytes;
   unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
   double* acc_lds = reinterpret_cast<double*>(wave_lds + kQCap * 64 * 4);          // [kAccSlots][3]
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned char* coop_base = wave_lds + kQCap * 64 * 4 + kAccSlots * 28 + kProfSlots * 8;
   unsigned long long* coop_t = reinterpret_cast<unsigned long long*>(coop_base);   // [64] closest t so far (bit pattern)
   unsigned long long* coop_w = coop_t + 64;                                        // [64] (original index << 32) | cold slot at that t
-  unsigned* coop_pair = reinterpret_cast<unsigned*>(coop_w + 64);                  // [kCoopList] lane | block << 6
-  unsigned* coop_surv = coop_pair + kCoopList;                                     // [kCoopList] lane | cold slot << 6
+  unsigned* coop_surv = reinterpret_cast<unsigned*>(coop_w + 64);                  // [kCoopList] lane | cold slot << 6
+  unsigned* coop_pair = coop_surv + kCoopList;                                     // [kCoopList] lane | block << 6 (BLOCKS variants only)
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     V3 radiance = v3(0.0, 0.0, 0.0);
     // kCoop: TOR_ACCEL_BLOCKS | TOR_ACCEL_F32 resolve their candidates COOPERATIVELY (all 64 lanes, active or not,
     // work through the wave's (ray, block) pairs and (ray, object) survivors: see the resolve section below)
-    constexpr bool kCoop = (F32 != 0) && (BLOCKS != 0);
+    constexpr bool kCoop = coop_variant(F32, BLOCKS);
     {
       // ================= (B) closest hit over all objects ==============================
       // hittables_lists.nim:48-55 with t_min = 0.001, t_max = Inf (render.nim:28)
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           } else if (F32 && BLOCKS && (seg_kind == 3 || seg_kind == 4)) {
             // the same boxes through the float32 slab test (tor_filter32.hpp): 8 floats per record via scalar loads
             cfptr rec = (cfptr)(uintptr_t)p.bnd32 + 8 * (long)(seg_begin + i);
-            if (kCoop && seg_count <= 64) {
+            if (seg_count <= 64) {
               box_kind = seg_kind;
               box_group0 = (unsigned)seg_block0;
               for (; i < seg_count; i += kBlock) {
@@ -711,6 +714,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           };
           // (B) one trip: pairs [base, base + n)
           auto trip_b = [&](unsigned base, unsigned n) {
+            if constexpr (BLOCKS != 0) {
             const bool mine = (unsigned)lane < n;
             const unsigned e = mine ? coop_pair[base + (unsigned)lane] : (unsigned)lane;
             const int src = (int)(e & 63u);
@@ -768,8 +772,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               coop_surv[at++] = (unsigned)src | (((unsigned)p.spatial_base + blk_id * kBlock + (unsigned)(7 - bb)) << 6);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
           };
           auto drain_b = [&](bool all) {
+            if constexpr (BLOCKS != 0)
             while (n_pairs != 0 && (all || n_pairs >= 64)) {
               const unsigned n = n_pairs < 64 ? n_pairs : 64;
               n_pairs -= n;
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
           for (;;) {
             unsigned kind = 3, m = 0, blk = 0;  // 3: nothing this trip
-            if (sup_mask != 0) {
+            if (BLOCKS != 0 && sup_mask != 0) {
               const int b = 31 - __builtin_clz(sup_mask);
               sup_mask &= ~(1u << b);
               const unsigned rec = sup_block * kBlock + (unsigned)(7 - b);  // super box `rec`: its block boxes are rec*8 .. rec*8+7
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               const int b = 31 - __builtin_clz(m);
               m &= ~(1u << b);
               const unsigned id = blk * kBlock + (unsigned)(7 - b);  // block id, or cold slot of a direct candidate
-              if (kind == 2) coop_pair[at_p++] = (unsigned)lane | (id << 6);
+              if (BLOCKS != 0 && kind == 2) coop_pair[at_p++] = (unsigned)lane | (id << 6);
               else coop_surv[at_s++] = (unsigned)lane | (id << 6);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1636,7 +1642,7 @@ static int clamp_w(int waves_per_simd) {
 static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? 1 : 0; }
 static size_t dynamic_lds(const KParams& p) {
-  return (size_t)wave_lds_bytes(wants_blocks(p), wants_blocks(p) && wants_f32(p)) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
+  return (size_t)wave_lds_bytes(wants_blocks(p), coop_variant(wants_f32(p), wants_blocks(p))) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
          (size_t)p.bnd32_lds_floats * 4;
 }
 
