@@ -158,7 +158,7 @@ typedef struct TorOptions {
   int32_t gather;       /* TOR_GATHER_* */
   int32_t devices[TOR_MAX_DEVICES];
   /* TOR_SEED_PIXEL only: which kernel walks the pixel chains (same canvas either way).
-   * TOR_PIXEL_KERNEL_AUTO: one wave per pixel on small frames (<= 163840 pixels per device; TOR_COOP_MAX_PIXELS),
+   * TOR_PIXEL_KERNEL_AUTO: one wave per pixel on small frames (<= 114688 pixels per device; TOR_COOP_MAX_PIXELS),
    * one lane per pixel otherwise.  LANE / WAVE force one of them (WAVE falls back to LANE when the scene does not
    * fit LDS). */
   int32_t pixel_kernel;

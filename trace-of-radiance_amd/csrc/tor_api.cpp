@@ -58,9 +58,10 @@ int fail_hip(hipError_t e, const char* what) {
 hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* cold_override) {
   const std::vector<double>& c = cold_override ? *cold_override : lay.cold;
   struct Part { const void* src; size_t bytes; size_t off; };
-  Part parts[6] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
+  Part parts[7] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
                    {lay.movy.data(), lay.movy.size() * 8, 0}, {lay.segs.data(), lay.segs.size() * 8, 0},
-                   {c.data(), c.size() * 8, 0},               {lay.hot32.data(), lay.hot32.size() * 4, 0}};
+                   {c.data(), c.size() * 8, 0},               {lay.hot32.data(), lay.hot32.size() * 4, 0},
+                   {lay.coop_trips.data(), lay.coop_trips.size() * 8, 0}};
   size_t total = 0;
   for (Part& p : parts) {
     p.off = total;
@@ -78,6 +79,7 @@ hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* c
   segs = (const double*)(b + parts[3].off);
   cold = (const double*)(b + parts[4].off);
   hot32 = (const float*)(b + parts[5].off);
+  coop_trips = (const double*)(b + parts[6].off);
   n_segs = lay.n_segs;
   n_sorted = (int)lay.n_sorted;
   has_f32 = false;
@@ -430,6 +432,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.cold = L.cold;
     p.n_cold_slots = L.n_sorted;
     p.coop_slots = (L.n_sorted + 63) / 64 * 64;
+    p.coop_trips = L.coop_trips;
     const int bpc = tor::coop_blocks_per_cu(p, o.arith);
     if (bpc > 0) {
       p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;

@@ -69,6 +69,7 @@ struct DeviceLayout {
   DeviceBuffer blob;
   const double *stat = nullptr, *mov = nullptr, *movy = nullptr, *segs = nullptr, *cold = nullptr;
   const float* hot32 = nullptr;
+  const double* coop_trips = nullptr;  // coop_pixel_kernel: 4 float64 per trip of 64 cold slots
   int n_segs = 0;
   int n_sorted = 0;  // cold slots (padded)
   bool has_f32 = false;
@@ -144,7 +145,7 @@ struct TorContext {
   int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
   // SEED_PIXEL frames of at most this many (local) pixels run coop_pixel_kernel (one wave per pixel: the frame is
   // too small to fill the machine with one lane per pixel chain).  TOR_COOP_MAX_PIXELS overrides; 0 = never.
-  long long coop_max_pixels = 163840;
+  long long coop_max_pixels = 114688;
 };
 
 namespace tor {

@@ -1325,8 +1325,10 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* soa = reinterpret_cast<double*>(smem_raw);
   const int n_pad = p.coop_slots;  // multiple of 64, >= cold slots
+  const int n_trips = n_pad >> 6;
   const int lane = threadIdx.x & 63;
-  // ---- stage the objects: cold record (16 float64) -> 10 arrays ----
+  // ---- stage the objects: cold record (16 float64) -> per trip of 64 slots, 10 arrays of 64 float64
+  //      [trip][array][lane]: every ds_read of the object loop is `lane * 8 + trip base` + an immediate offset ----
   for (int k = threadIdx.x; k < n_pad; k += kThreads) {
     double c[kCoopArrays] = {0, 0, 0, 0, 0, 0, 0, 1.0, -1.0, 0};  // padding: never hit (r^2 = -1 -> discriminant < 0)
     if (k < p.n_cold_slots) {
@@ -1334,11 +1336,34 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
       c[0] = r[0]; c[1] = r[1]; c[2] = r[2]; c[3] = r[3]; c[4] = r[4]; c[5] = r[5];
       c[6] = r[7]; c[7] = r[8]; c[8] = r[15]; c[9] = r[13];
     }
+    double* dst = soa + (size_t)(k >> 6) * (kCoopArrays * 64) + (k & 63);
 #pragma unroll
-    for (int a = 0; a < kCoopArrays; ++a) soa[a * n_pad + k] = c[a];
+    for (int a = 0; a < kCoopArrays; ++a) dst[a * 64] = c[a];
   }
   __syncthreads();
-  const ldptr L = (ldptr)soa;
+  const ldptr L = (ldptr)soa + lane;  // + trip * (kCoopArrays * 64) + array * 64
+  // the trip table (tor_scene.cpp) into scalar registers once: 2 bits of kind per trip (scenes of up to 2048 cold
+  // slots; larger ones run every trip through the general path), and the movers' (time0, time1 - time0) when all
+  // uniform trips share one -- then a query divides for the time fraction exactly once
+  unsigned long long kinds = 0;
+  bool one_group = true, have_group = false;
+  double sg_t0 = 0.0, sg_dt = 1.0;
+  {
+    const cdptr trips = as_const(p.coop_trips);
+    for (int t = 0; t < n_trips; ++t) {
+      int kind = (int)trips[4 * t + 0];
+      if (t >= 32) kind = 3;
+      if (kind == 1 || kind == 2) {
+        const double t0 = trips[4 * t + 1], dt = trips[4 * t + 2];
+        if (!have_group) { sg_t0 = t0; sg_dt = dt; have_group = true; }
+        else if (t0 != sg_t0 || dt != sg_dt) one_group = false;
+      }
+      if (t < 32) kinds |= (unsigned long long)kind << (2 * t);
+    }
+    if (!one_group)  // several time groups: the uniform fast paths would need a division per trip -> general path
+      for (int t = 0; t < n_trips && t < 32; ++t)
+        if (((kinds >> (2 * t)) & 3) != 0) kinds |= 3ull << (2 * t);
+  }
   const double w_div = (double)(p.ncols - 1);  // render.nim:64
   const double h_div = (double)(p.nrows - 1);
   const cdptr cold = as_const(p.cold);
@@ -1375,24 +1400,8 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
         const double a = (ARITH == 0) ? dx * dx + dy * dy + dz * dz : fma_(dz, dz, fma_(dy, dy, dx * dx));  // spheres.nim:30
         double best_t = __builtin_inf(), best_f = 0.0;
         int best_slot = -1, best_orig = 0x7fffffff;
-        double g_t0 = 0.0, g_dt = 0.0, g_f = 0.0;  // fraction of the last time group seen (moving_spheres.nim:42)
-        bool g_valid = false;
-        for (int k = lane; k < n_pad; k += 64) {
-          double cx = L[0 * n_pad + k], cy = L[1 * n_pad + k], cz = L[2 * n_pad + k];
-          const double r2 = L[8 * n_pad + k];
-          const int flags = (int)__double_as_longlong(L[9 * n_pad + k]);
-          double f = 0.0;
-          if (flags & 1) {
-            const double t0 = L[6 * n_pad + k], dt = L[7 * n_pad + k];
-            if (!g_valid || t0 != g_t0 || dt != g_dt) {
-              g_f = (time - t0) / dt;
-              g_t0 = t0; g_dt = dt; g_valid = true;
-            }
-            f = g_f;
-            const double ex = L[3 * n_pad + k], ey = L[4 * n_pad + k], ez = L[5 * n_pad + k];
-            if (ARITH == 0) { cx = cx + ex * f; cy = cy + ey * f; cz = cz + ez * f; }  // moving_spheres.nim:43
-            else { cx = fma_(ex, f, cx); cy = fma_(ey, f, cy); cz = fma_(ez, f, cz); }
-          }
+        // exact test of one object (spheres.nim:28-49) and the order-independent closest-hit update
+        auto test_object = [&](int k, double cx, double cy, double cz, double r2, double f) {
           const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
           double hb, cc, disc;
           if (ARITH == 0) {
@@ -1418,14 +1427,54 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
               if (sol < best_t || (sol == best_t && orig < best_orig)) { best_t = sol; best_slot = k; best_orig = orig; best_f = f; }
             }
           }
+        };
+        // One trip = 64 consecutive cold slots, one per lane.  The host classified every trip (tor_scene.cpp): the
+        // common cases -- nothing moves / everything moves along y within one (time0, time1) / everything moves
+        // within one (time0, time1) -- run without per-object branches, and the time fraction is divided once per
+        // (time0, time1) and query (moving_spheres.nim:42: the same operands give the same quotient).
+        const double g_t0 = sg_t0, g_dt = sg_dt;
+        const double g_f = have_group ? (time - sg_t0) / sg_dt : 0.0;
+        for (int t = 0; t < n_trips; ++t) {
+          const ldptr T = L + t * (kCoopArrays * 64);
+          const int k = t * 64 + lane;
+          const int kind = (t < 32) ? (int)((kinds >> (2 * t)) & 3) : 3;
+          if (kind == 0) {
+            test_object(k, T[0 * 64], T[1 * 64], T[2 * 64], T[8 * 64], 0.0);
+            continue;
+          }
+          if (kind != 3) {
+            const double f = g_f;
+            double cx = T[0 * 64], cy = T[1 * 64], cz = T[2 * 64];
+            if (kind == 1) {  // center1.x == center0.x and center1.z == center0.z: c0 + f * 0 == c0
+              cy = (ARITH == 0) ? cy + T[4 * 64] * f : fma_(T[4 * 64], f, cy);
+            } else if (ARITH == 0) {
+              cx = cx + T[3 * 64] * f; cy = cy + T[4 * 64] * f; cz = cz + T[5 * 64] * f;  // moving_spheres.nim:43
+            } else {
+              cx = fma_(T[3 * 64], f, cx); cy = fma_(T[4 * 64], f, cy); cz = fma_(T[5 * 64], f, cz);
+            }
+            test_object(k, cx, cy, cz, T[8 * 64], f);
+          } else {  // mixed trip: per-object kind and time group
+            double cx = T[0 * 64], cy = T[1 * 64], cz = T[2 * 64];
+            double f = 0.0;
+            if ((int)__double_as_longlong(T[9 * 64]) & 1) {
+              const double t0 = T[6 * 64], dt = T[7 * 64];
+              f = (have_group && t0 == g_t0 && dt == g_dt) ? g_f : (time - t0) / dt;
+              if (ARITH == 0) { cx = cx + T[3 * 64] * f; cy = cy + T[4 * 64] * f; cz = cz + T[5 * 64] * f; }
+              else { cx = fma_(T[3 * 64], f, cx); cy = fma_(T[4 * 64], f, cy); cz = fma_(T[5 * 64], f, cz); }
+            }
+            test_object(k, cx, cy, cz, T[8 * 64], f);
+          }
         }
         const double t_min = wave_min_f64(best_t);
         if (!(t_min < __builtin_inf())) {
           radiance = sky(d, att);  // render.nim:41-45
           break;
         }
-        const int o_min = wave_min_i32(best_t == t_min ? best_orig : 0x7fffffff);
-        const unsigned long long win = ballot64(best_t == t_min && best_orig == o_min);
+        unsigned long long win = ballot64(best_t == t_min);
+        if (win & (win - 1)) {  // several lanes at the same t (duplicate objects): the lowest original index wins
+          const int o_min = wave_min_i32(best_t == t_min ? best_orig : 0x7fffffff);
+          win = ballot64(best_t == t_min && best_orig == o_min);
+        }
         const int wl = (int)__builtin_ctzll(win);
         const int slot = __builtin_amdgcn_readlane(best_slot, wl);
         const unsigned long long fb = (unsigned long long)__double_as_longlong(best_f);

@@ -71,6 +71,7 @@ struct KParams {
   const double* cam_dev;  // 24 float64, TorCamera layout (cameras.nim:15-22)
   // coop_pixel_kernel (one wave per pixel): number of cold slots of the flat layout and that number padded to 64
   int n_cold_slots, coop_slots;
+  const double* coop_trips;  // 4 float64 per trip of 64 slots {kind, time0, time1 - time0, 0} (tor_scene.hpp)
 };
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,

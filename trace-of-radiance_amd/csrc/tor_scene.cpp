@@ -279,6 +279,34 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   }
   out.n_segs = (int)(out.segs.size() / 8);
   if (out.segs.empty()) out.segs.assign(8, 0.0);
+  // trip table of the one-wave-per-pixel kernel
+  const size_t n_trips = (out.n_sorted + 63) / 64;
+  out.coop_trips.assign(4 * n_trips + 4, 0.0);
+  for (size_t t = 0; t < n_trips; ++t) {
+    bool any_mover = false, any_static = false, y_only = true, same_group = true, sane = true;
+    uint64_t g0 = 0, g1 = 0;
+    double t0 = 0.0, dt = 1.0;
+    for (size_t k = 64 * t; k < 64 * (t + 1); ++k) {
+      if (k >= out.n_sorted) { any_static = true; continue; }  // beyond the list: staged as never-hit static records
+      const double* cr = &out.cold[16 * k];
+      int64_t flags;
+      std::memcpy(&flags, &cr[13], 8);
+      if (!(flags & 1)) { any_static = true; continue; }
+      uint64_t b0, b1;
+      std::memcpy(&b0, &cr[7], 8); std::memcpy(&b1, &cr[8], 8);
+      if (!any_mover) { g0 = b0; g1 = b1; t0 = cr[7]; dt = cr[8]; }
+      else if (b0 != g0 || b1 != g1) same_group = false;
+      any_mover = true;
+      if (!(cr[3] == 0.0 && cr[5] == 0.0)) y_only = false;
+      if (!std::isfinite(cr[7]) || !std::isfinite(cr[8]) || cr[8] == 0.0) sane = false;
+    }
+    double kind = 3.0;
+    if (!any_mover) kind = 0.0;
+    else if (!any_static && same_group && sane) kind = y_only ? 1.0 : 2.0;
+    out.coop_trips[4 * t + 0] = kind;
+    out.coop_trips[4 * t + 1] = t0;
+    out.coop_trips[4 * t + 2] = dt;
+  }
   return true;
 }
 

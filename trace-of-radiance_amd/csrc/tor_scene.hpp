@@ -17,6 +17,10 @@ struct HostLayout {
   std::vector<float> hot32;  // TOR_ACCEL_F32 segments (kinds 5/6/7): packed pair records, see tor_kernels.hpp
   int n_segs = 0;
   size_t n_sorted = 0;  // cold slots (padded)
+  // coop_pixel_kernel walks the cold slots 64 at a time ("trips"); 4 float64 per trip {kind, time0, time1 - time0, 0}:
+  // kind 0 = no slot of the trip moves, 1 = all move along y only and share (time0, time1), 2 = all move and share
+  // (time0, time1), 3 = mixed (per-object handling)
+  std::vector<double> coop_trips;
 };
 
 // TOR_ACCEL_F32: objects that qualify (tor_filter32.hpp: f32_eligible, and not farther than far_limit from
