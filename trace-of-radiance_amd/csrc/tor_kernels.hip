@@ -121,8 +121,11 @@ constexpr int coop_bytes(int blocks) { return (blocks ? 2 : 1) * kCoopList * 4 +
 constexpr int wave_lds_bytes(int blocks, int coop = 0) {
   return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) : 0);
 }
-// which kernel variants resolve cooperatively: every one except block culling with float64 expansion (F32 = 0, BLOCKS = 1)
-constexpr bool coop_variant(int f32, int blocks) { return blocks == 0 || f32 != 0; }
+// Which kernel variants resolve cooperatively: TOR_ACCEL_BLOCKS | TOR_ACCEL_F32.  (The code also runs the variants
+// without boxes -- `blocks == 0 || f32 != 0` passes every parity test -- but there the candidates are few (1.25-1.43
+// per query): a pooled trip costs twice a per-lane trip, the resolve share stays at 5-6 % and the extra LDS and
+// registers cost the float64 brute force 2 % (C3 1190 -> 1163 Msamples/s).  Measured, not kept.)
+constexpr bool coop_variant(int f32, int blocks) { return blocks != 0 && f32 != 0; }
 static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0 && wave_lds_bytes(1, 1) % 16 == 0 && wave_lds_bytes(0, 1) % 16 == 0,
               "keep LDS carve-outs 16-byte aligned");
 
