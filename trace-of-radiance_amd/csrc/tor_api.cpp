@@ -512,6 +512,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     if (v32 && hacc.sp32) {
       p.shot32 = (const float*)ctx->d_accel[v32].hot32.ptr;
       p.shot32_stride = hacc.hot32_stride;
+      p.shot32_block_stride = hacc.hot32_block_stride;
       p.sp_mc0max = hacc.sp_mc0max; p.sp_dcmax = hacc.sp_dcmax;
       p.sp_t0 = hacc.sp_t0; p.sp_dt = hacc.sp_dt;
     }

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               using T10 = std::integral_constant<int, 10>;
               using T12 = std::integral_constant<int, 12>;
               using T16 = std::integral_constant<int, 16>;
-              const size_t off = (size_t)blk_id * (size_t)(p.shot32_stride * (kBlock / 2));
+              const size_t off = (size_t)blk_id * (size_t)p.shot32_block_stride;
               if (p.shot32_lds_floats > 0) {
                 if (p.shot32_stride == 12) filter_block(shot32_lds + off, T12{});
                 else if (p.shot32_stride == 10) filter_block(shot32_lds + off, T10{});
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 if (stats_on) atomicAdd(&prof_lds[kStCand], (unsigned long long)kBlock);
                 if constexpr (F32 != 0) {
                   // (the host pairs the float32 kernel variant with float32 block records, or with no blocks at all)
-                  const size_t off = (size_t)blk_id * (size_t)(p.shot32_stride * (kBlock / 2));
+                  const size_t off = (size_t)blk_id * (size_t)p.shot32_block_stride;
                   if (p.shot32_lds_floats > 0) {
                     if (p.shot32_stride == 12) expand32(shot32_lds + off, T12{}, blk_id);
                     else if (p.shot32_stride == 10) expand32(shot32_lds + off, T10{}, blk_id);

@@ -46,6 +46,7 @@ struct KParams {
   // per block), replacing shot/sgrp in the block expansion; null -> float64 expansion
   const float* shot32;
   int shot32_stride;      // 10 | 12 | 16 floats per pair
+  int shot32_block_stride;  // floats per block of 4 pairs (4 * shot32_stride + padding)
   int shot32_lds_floats;  // > 0: copy that many floats of shot32 into LDS per workgroup
   float sp_mc0max, sp_dcmax;
   const float* bnd32;     // float32 boxes (8 floats per record, same indices as bnd): {lo.x hi.x lo.y hi.y lo.z hi.z 0 0} - org

@@ -460,9 +460,13 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
       out.hot32_stride = !any_mover ? 10 : (y_only ? 12 : 16);
       const int st = out.hot32_stride;
       const size_t slots = n_bnd_slots * kPad;
-      out.hot32.assign(slots / 2 * (size_t)st + 32, 0.0f);
+      // A block's four pair records are followed by 4 floats of padding: the per-lane reads of the block expansion
+      // (64 lanes, 64 different blocks) then start at 16 different LDS bank groups instead of 4 (st = 12: 48 floats
+      // per block, 48 mod 64 takes 4 values; 52 takes 16) -- half of the LDS cycles were bank conflicts.
+      out.hot32_block_stride = 4 * st + 4;
+      out.hot32.assign(slots / kPad * (size_t)out.hot32_block_stride + 32, 0.0f);
       for (size_t k = 0; k < slots; ++k) {
-        float* rec = &out.hot32[(k / 2) * (size_t)st];
+        float* rec = &out.hot32[(k / kPad) * (size_t)out.hot32_block_stride + ((k % kPad) / 2) * (size_t)st];
         const int h = (int)(k & 1);
         const HostAccel::Obj* o = k < out.spatial.size() && out.spatial[k].valid ? &out.spatial[k] : nullptr;
         if (!o) {

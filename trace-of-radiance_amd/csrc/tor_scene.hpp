@@ -61,6 +61,7 @@ struct HostAccel {
   bool sp32 = false;
   std::vector<float> hot32;
   int hot32_stride = 10;
+  int hot32_block_stride = 40;  // floats from one block's records to the next (4 pairs + padding against LDS bank conflicts)
   double sp_t0 = 0.0, sp_dt = 1.0;      // the movers' time group
   float sp_mc0max = 0.0f, sp_dcmax = 0.0f;  // max |c0 - origin| and |dc| over the spatial objects (rounded up)
 };
