@@ -412,6 +412,29 @@ def main():
             flag = torch.tensor([1 if lib_ok else 0], dtype=torch.int64, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             lib_ok = bool(flag.item())
+            if lib_ok:
+                # prove the library's gather on a small frame before the clock depends on it: every rank renders its
+                # shard of a 64-row frame, rank 0 gathers and compares with the frame it renders alone
+                try:
+                    th, tw = 64, 96
+                    small = torch.zeros((th, tw, 3), dtype=torch.float64, device="cuda")
+                    ctx.render_gather_device(cam, th, tw, 2, 2.2, 8, opt, 0, small.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    ok = 1
+                    if rank == 0:
+                        alone = torch.zeros_like(small)
+                        ctx.render_device(cam, th, tw, 2, 2.2, 8, tor.make_options(seeding=seeding, arith=arith, accel=accel),
+                                          alone.data_ptr(), stream)
+                        torch.cuda.synchronize()
+                        ok = int(torch.equal(alone, small))
+                except Exception as e:  # noqa
+                    print(f"[bench rank {rank}] library gather failed its self-check ({e}); using torch.distributed", file=sys.stderr, flush=True)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                lib_ok = bool(flag.item())
+                if not lib_ok:
+                    ctx.comm_destroy()
         if lib_ok:
             gather_kind = "tor_render_gather_device: RCCL send/recv gather to rank 0 inside libtor_mi355x + de-interleave kernel"
         else:

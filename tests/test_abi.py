@@ -66,3 +66,34 @@ def test_rendering_fails_loudly_without_a_device(tor):
     assert np.all(cv.pixels == 3.0)
     with pytest.raises(tor.TorError):
         tor.Context()
+
+
+def test_options_layout_and_versions(tor):
+    """TorOptions: 108 bytes; the 32-byte round-1 layout is still accepted (its fields are a prefix), anything else
+    is refused before a device is touched (this box has none: a well-formed call gets TOR_ERR_NO_DEVICE, never a
+    CPU fallback)."""
+    import ctypes as C
+    assert C.sizeof(tor.Options) == 108 and tor.Options.device_count.offset == 32 and tor.Options.pixel_kernel.offset == 104
+    scene = tor.random_scene(0xFACADE)
+    cam = tor.camera()
+    cv = tor.new_canvas(4, 4, 1, 2.2)
+    cv.pixels[:] = 5.0
+    L = tor.lib()
+    cs = cv.struct()
+    codes = {}
+    for size in (33, 0, 200, 32, 108):
+        o = tor.make_options()
+        o.struct_size = size
+        codes[size] = L.tor_render_opt(C.byref(cs), C.byref(cam), scene.list(), 50, C.byref(o))
+    assert codes[33] == -1 and codes[0] == -1 and codes[200] == -1            # TOR_ERR_INVALID_ARGUMENT
+    import torch
+    if not torch.cuda.is_available():
+        assert codes[108] == -2 and codes[32] == -2                          # TOR_ERR_NO_DEVICE: there is no CPU fallback
+        assert b"no CPU fallback" in L.tor_last_error()
+        assert (cv.pixels == 5.0).all()                                       # never a partial canvas
+    for bad in (dict(device_count=17), dict(gather=9), dict(pixel_kernel=3), dict(device_count=2, shard_count=2)):
+        o = tor.make_options()
+        for k, v in bad.items():
+            setattr(o, k, v)
+        assert L.tor_render_opt(C.byref(cs), C.byref(cam), scene.list(), 50, C.byref(o)) == -1, bad
+    assert L.tor_render_ptr(C.byref(cs), C.byref(cam), None, 50) == -1
