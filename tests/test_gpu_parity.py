@@ -16,6 +16,10 @@ TOL = 1e-5
 
 
 def _render(tor, scene, cam, h, w, spp, depth=50, **opt):
+    # small TOR_SEED_PIXEL frames would run the wave-per-pixel kernel, which ignores `accel`: a test that names an
+    # acceleration means the lane kernel (the wave kernel has its own tests and is what every accel-less call below runs)
+    if "accel" in opt and opt.get("seeding", tor.SEED_PIXEL) == tor.SEED_PIXEL and "pixel_kernel" not in opt:
+        opt["pixel_kernel"] = tor.PIXEL_KERNEL_LANE
     cv = tor.new_canvas(h, w, spp, 2.2)
     tor.render(cv, cam, scene.list(), depth, tor.make_options(**opt) if opt else None)
     return cv

@@ -60,9 +60,17 @@ def main():
             canv = []
             for accel in (0, 1, 2, 3):
                 cv = tor.new_canvas(h, w, spp, 2.2)
-                tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, accel=accel))
+                # (pixel_kernel=1: the lane kernel -- the wave-per-pixel kernel small frames would otherwise get ignores accel)
+                tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, accel=accel, pixel_kernel=1))
                 canv.append(cv.pixels.copy())
                 n_renders += 1
+            if seeding == 0:  # the wave-per-pixel kernel (TorOptions.pixel_kernel = 2) against the lane kernel's brute force
+                cv = tor.new_canvas(h, w, spp, 2.2)
+                tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=0, accel=0, pixel_kernel=2))
+                n_renders += 1
+                if not np.array_equal(canv[0], cv.pixels, equal_nan=True):
+                    bad += 1
+                    print(f"MISMATCH scene {n_scenes} (n={len(recs)}) wave-per-pixel kernel: {int((canv[0] != cv.pixels).sum())} values differ", flush=True)
             for accel in (1, 2, 3):
                 if not np.array_equal(canv[0], canv[accel], equal_nan=True):
                     bad += 1
