@@ -140,25 +140,39 @@ TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v ocx, f2v ocy
 // whose exact test passes.  NaN (0 * inf on an axis the ray is parallel to, or a NaN padding box) is dropped by
 // min/max exactly as in the float64 test.
 struct BoxRay32 {
-  f2v ax, ay, az;  // (-o^ - e, -o^ + e) per axis
+  f2v ax, ay, az;  // (-o^ - e, -o^ + e) / d^ per axis (the quotient is formed per ray, see slab_bit32)
   f2v ix, iy, iz;  // 1/d^ per axis, both halves
 };
 
 TOR_HD BoxRay32 make_box_ray32(const RayF32& r, float bmax) {
   BoxRay32 b;
   const float e = 3.0f * kU32 * (r.ro + bmax);
-  b.ax = (f2v){-r.ox - e, -r.ox + e};
-  b.ay = (f2v){-r.oy - e, -r.oy + e};
-  b.az = (f2v){-r.oz - e, -r.oz + e};
-  b.ix = splat2(1.0f / r.dx);
-  b.iy = splat2(1.0f / r.dy);
-  b.iz = splat2(1.0f / r.dz);
+  // An axis the ray is (nearly) parallel to -- |1/d^| = inf or so large that the per-ray product could overflow --
+  // must not constrain: in the fused form box * inf + (-o^) * inf is inf - inf = NaN exactly when the origin lies
+  // between the planes, and max(-inf, NaN) would then report "leaves before it enters".  Such an axis gets
+  // 1/d^ := 0 and the addend (-inf, +inf): t = (-inf, +inf), no constraint (a NaN padding box still yields NaN).
+  const float inf = __builtin_inff();
+  auto axis = [&](float o, float d, f2v& a, f2v& i) {
+    const float id = 1.0f / d;
+    const bool open = !(__builtin_fabsf(id) <= 0x1p100f);  // inf, NaN or huge
+    i = splat2(open ? 0.0f : id);
+    a = open ? (f2v){-inf, inf} : (f2v){(-o - e) * id, (-o + e) * id};
+  };
+  axis(r.ox, r.dx, b.ax, b.ix);
+  axis(r.oy, r.dy, b.ay, b.iy);
+  axis(r.oz, r.dz, b.az, b.iz);
   return b;
 }
 
 // 1: the ray may touch the box {bx = (lo.x, hi.x), by, bz}; 0: it cannot.
 TOR_HD unsigned slab_bit32(const BoxRay32& b, f2v bx, f2v by, f2v bz) {
-  const f2v tx = (bx + b.ax) * b.ix, ty = (by + b.ay) * b.iy, tz = (bz + b.az) * b.iz;
+  // t = (box - o^ -+ e) / d^ as ONE fused multiply-add per axis: box * (1/d^) + ((-o^ -+ e) * (1/d^)), the second product
+  // formed once per ray.  Against the two-step form this moves one rounding: the per-ray product carries u |o^ +- e| |1/d^|,
+  // which is a box-coordinate error of u (|o-P| + e) -- inside the inflation e = 3 u (|o-P| + max|box|), whose budget
+  // so far only spent u |o-P| (rounding of o^) + u (|box| + |o^|) (the subtraction, now exact inside the fma).  With
+  // d^ = 0 an axis gives inf - inf = NaN more often than before (whenever box and origin terms differ in sign); NaN is
+  // dropped by min/max, i.e. that axis stops constraining: conservative.
+  const f2v tx = fma2(bx, b.ix, b.ax), ty = fma2(by, b.iy, b.ay), tz = fma2(bz, b.iz, b.az);
   const float tx0 = tx.x, tx1 = tx.y, ty0 = ty.x, ty1 = ty.y, tz0 = tz.x, tz1 = tz.y;
   const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)),
                                      __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
