@@ -158,9 +158,11 @@ typedef struct TorOptions {
   int32_t gather;       /* TOR_GATHER_* */
   int32_t devices[TOR_MAX_DEVICES];
   /* TOR_SEED_PIXEL only: which kernel walks the pixel chains (same canvas either way).
-   * TOR_PIXEL_KERNEL_AUTO: one wave per pixel on small frames (<= 114688 pixels per device; TOR_COOP_MAX_PIXELS),
-   * one lane per pixel otherwise.  LANE / WAVE force one of them (WAVE falls back to LANE when the scene does not
-   * fit LDS). */
+   * TOR_PIXEL_KERNEL_AUTO: frames of 16 K .. 625 K pixels (per device) with both exact accelerations and >= 32 spp
+   * are SHARED -- the tiles that carry the largest part of a probed cost go to the one-wave-per-pixel kernel on a
+   * second stream, the one-lane-per-pixel kernel renders the rest at the same time (TOR_SPLIT_FRAC overrides the
+   * fraction, 0 = off); otherwise one wave per pixel up to 114688 pixels (TOR_COOP_MAX_PIXELS), one lane per pixel
+   * above.  LANE / WAVE force one kernel for the whole frame (WAVE falls back to LANE when the scene does not fit LDS). */
   int32_t pixel_kernel;
 } TorOptions;
 

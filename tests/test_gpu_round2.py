@@ -396,3 +396,32 @@ def test_wave_per_pixel_kernel_matches_lane_kernel_and_oracle(tor, oracle, ref_s
     # the reference's own main() (C1) through both kernels
     c1 = both(scene, cam, 216, 384, 100, accel=3)
     _exact(c1, oracle.render(216, 384, 100, ref_camera, objs, seeding=0, math=1, arith=0).pixels)
+
+
+def test_split_mode_lane_and_wave_kernels_share_a_frame(tor, oracle, ref_scene, ref_camera):
+    """Mid-size TOR_SEED_PIXEL frames with both accelerations (tor_render()'s default) run in split mode: the cost
+    probe orders the tiles, the most expensive ones go to the wave-per-pixel kernel on a second stream, the lane
+    kernel renders the others at the same time.  Same canvas as the lane kernel alone and as the oracle -- for a
+    pixel count that is not a multiple of the 64-pixel tile, for a row shard, and for the reference's main()."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    for (h, w, spp, shard) in ((129, 131, 33, None), (216, 384, 100, None), (300, 171, 32, (1, 2, 4))):
+        opt = dict(accel=3)
+        if shard:
+            opt.update(shard_index=shard[0], shard_count=shard[1], row_tile=shard[2])
+        auto = tor.new_canvas(h, w, spp, 2.2)
+        auto.pixels[:] = -1.0
+        tor.render(auto, cam, scene.list(), 50, tor.make_options(**opt))                      # AUTO -> split mode
+        lane = tor.new_canvas(h, w, spp, 2.2)
+        lane.pixels[:] = -1.0
+        tor.render(lane, cam, scene.list(), 50, tor.make_options(pixel_kernel=tor.PIXEL_KERNEL_LANE, **opt))
+        assert np.array_equal(auto.pixels, lane.pixels), (h, w, spp, shard)
+        rows = tor.shard_rows(h, shard[2], shard[0], shard[1]) if shard else np.arange(h)
+        want = oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=1, arith=0).pixels
+        _exact(auto.pixels[rows], want[rows])
+    # twice in a row on one context (ring slots, second stream, events), interleaved with a plain launch
+    a = tor.new_canvas(216, 384, 40, 2.2); b = tor.new_canvas(216, 384, 40, 2.2); c = tor.new_canvas(64, 64, 4, 2.2)
+    tor.render(a, cam, scene.list(), 50)
+    tor.render(c, cam, scene.list(), 50)
+    tor.render(b, cam, scene.list(), 50)
+    assert np.array_equal(a.pixels, b.pixels)

@@ -272,6 +272,9 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
   if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
   if (const char* c = std::getenv("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
+  if (const char* c = std::getenv("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
+  if (const char* c = std::getenv("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
     for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
   e = ctx->counters.ensure(TorContext::kRing * 8 * sizeof(unsigned long long));
@@ -312,6 +315,11 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->staging.release();
   for (hipEvent_t ev : ctx->chunk_events) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  for (int i = 0; i < TorContext::kRing; ++i) {
+    if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
   for (int i = 0; i < TorContext::kRing; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
     if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -423,8 +431,19 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   tor::KParams p{};
   // Small SEED_PIXEL frames: one wave per pixel (coop_pixel_kernel) -- the lane-per-pixel kernel would be bound by
   // the latency of the longest pixel chain.  Same canvas bit for bit; needs only the float64 flat layout.
+  // Split fraction: the wave-per-pixel kernel saturates at ~285 Msamples/s, the lane kernel (with both exact
+  // accelerations) has a latency floor of ~0.18 ms per sample-per-pixel; the two finish together when the wave
+  // kernel takes about 50 000 pixels' worth of the cost, at most 45 % (measured: tools/split_sweep.py).
+  float split_frac = ctx->split_frac;
+  if (split_frac < 0.0f) {
+    split_frac = (o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) ? 50000.0f / (float)npix : 0.0f;
+    if (split_frac > 0.45f) split_frac = 0.45f;
+    if (split_frac < 0.08f) split_frac = 0.0f;
+  }
+  const bool split_applies = o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
+                             npix >= ctx->split_min_pixels && npix <= ctx->split_max_pixels && !ctx->collect_stats && ctx->n_objects > 0;
   const bool want_wave_kernel = o.pixel_kernel == TOR_PIXEL_KERNEL_WAVE ||
-                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels);
+                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels && !split_applies);
   if (o.seeding == TOR_SEED_PIXEL && !ctx->collect_stats && want_wave_kernel && ctx->n_objects > 0) {
     const int rc = tor::ensure_layouts(ctx, 0);
     if (rc != TOR_OK) return rc;
@@ -620,8 +639,52 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     const int pblocks = (int)((pw + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
     pp.n_waves = (unsigned)(pblocks * (tor::kThreads / 64));
     HIP_TRY(tor::launch_probe(pp, pblocks, stream));
-    HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned*)tile_order.ptr, (int)n_tiles, stream));
+    // Split mode (mid-size frames): the lane kernel is bound by its longest pixel chains, the wave-per-pixel kernel by
+    // its throughput -- so the most expensive tiles (split_frac of the probed cost) go to the wave kernel on a second
+    // stream while the lane kernel renders the rest.  Disjoint pixels, same arithmetic: same canvas.
+    tor::KParams wk{};
+    bool split = false;
+    if (split_applies) {
+      const int rc = tor::ensure_layouts(ctx, 0);
+      if (rc != TOR_OK) return rc;
+      const tor::DeviceLayout& L = ctx->flat[0];
+      wk = p;
+      wk.cold = L.cold;
+      wk.n_cold_slots = L.n_sorted;
+      wk.coop_slots = (L.n_sorted + 63) / 64 * 64;
+      wk.coop_trips = L.coop_trips;
+      wk.order = (const unsigned*)tile_order.ptr;
+      wk.split = slot_counters + 6;
+      wk.work_counter = slot_counters + 7;
+      wk.stats = nullptr;
+      wk.wave_log = nullptr;
+      split = tor::coop_blocks_per_cu(wk, o.arith) > 0;
+    }
+    HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned*)tile_order.ptr, (int)n_tiles, split ? split_frac : 0.0f,
+                                   split ? slot_counters + 6 : nullptr, split ? slot_counters : nullptr, stream));
     p.order = (const unsigned*)tile_order.ptr;
+    if (split) {
+      if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      if (!ctx->ev_fork[slot]) {
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[slot], hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+      HIP_TRY(hipEventRecord(ctx->ev_fork[slot], stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork[slot], 0));
+      const long long wave_blocks = (long long)ctx->num_cus * tor::coop_blocks_per_cu(wk, o.arith);
+      HIP_TRY(tor::launch_coop(wk, o.arith, (int)wave_blocks, ctx->stream2));
+      HIP_TRY(hipEventRecord(ctx->ev_join[slot], ctx->stream2));
+      HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));
+      HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_join[slot], 0));
+      HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+      ctx->launches += 1;
+      ctx->last_slot = slot;
+      ctx->timing_valid = true;
+      ctx->last_samples = (int64_t)npix * spp;
+      HIP_TRY(tor::launch_finalize(d_pixels, n_values, 1.0 / (double)spp, 1.0 / (double)gamma_correction, stream));
+      return TOR_OK;
+    }
   }
   HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
   HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));

@@ -146,6 +146,13 @@ struct TorContext {
   // SEED_PIXEL frames of at most this many (local) pixels run coop_pixel_kernel (one wave per pixel: the frame is
   // too small to fill the machine with one lane per pixel chain).  TOR_COOP_MAX_PIXELS overrides; 0 = never.
   long long coop_max_pixels = 114688;
+  // Split mode for SEED_PIXEL frames between split_min_pixels and split_max_pixels (when the cost probe runs): the
+  // tiles that carry split_frac of the probed cost go to the wave-per-pixel kernel on stream2, the lane kernel takes
+  // the rest concurrently.  TOR_SPLIT_FRAC (0 = off), TOR_SPLIT_MIN_PIXELS, TOR_SPLIT_MAX_PIXELS.
+  float split_frac = -1.0f;  // < 0: automatic (tor_render_device), 0: off
+  long long split_min_pixels = 16384, split_max_pixels = 1048576;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork[kRing] = {}, ev_join[kRing] = {};
 };
 
 namespace tor {

@@ -1370,6 +1370,10 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
   const double w_div = (double)(p.ncols - 1);  // render.nim:64
   const double h_div = (double)(p.nrows - 1);
   const cdptr cold = as_const(p.cold);
+  // work items: every pixel of the (shard's) frame, or -- split mode -- the pixels of the first *p.split tiles of the
+  // cost-ordered list (the lane kernel renders the others at the same time)
+  const unsigned long long n_items =
+      p.split != nullptr ? bcast_first_u64(*(const volatile unsigned long long*)p.split) * (unsigned long long)kTilePixels : (unsigned long long)p.n_pixels;
 
   for (;;) {
     // No `if (lane == 0)` around the fetch or the store below: with both in the loop the compiler threads the two
@@ -1378,8 +1382,12 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
     // adds 1 for lane 0 and 0 for the others (one aggregated atomic), the store writes 64 identical values.
     unsigned long long pl64 = atomicAdd(p.work_counter, lane == 0 ? 1ull : 0ull);
     pl64 = bcast_first_u64(pl64);
-    if (pl64 >= (unsigned long long)p.n_pixels) break;
-    const unsigned pl = (unsigned)pl64;
+    if (pl64 >= n_items) break;
+    unsigned pl = (unsigned)pl64;
+    if (p.split != nullptr) {  // the k-th item is pixel (k mod 64) of the (k / 64)-th most expensive tile
+      pl = p.order[pl64 >> 6] * (unsigned)kTilePixels + (unsigned)(pl64 & 63);
+      if (pl >= p.n_pixels) continue;  // the frame's last tile may be partial
+    }
     const unsigned lrow = pl / (unsigned)p.ncols;
     const int col = (int)(pl - lrow * (unsigned)p.ncols);
     const unsigned tile = lrow / (unsigned)p.row_tile;
@@ -1544,7 +1552,11 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
 // chains must start at t = 0).  One workgroup; the order of equal-cost tiles is irrelevant (the
 // schedule never changes a pixel's value).
 constexpr int kCostBins = 8192;
-__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* cost, unsigned* order, int n_tiles) {
+// With split_frac > 0 it also cuts the cost-descending list: the first K tiles carry split_frac of the probed cost
+// (the expensive pixel chains: they go to coop_pixel_kernel, one wave per pixel), the rest stays with the lane
+// kernel, whose work counter is therefore started at tile K.  K is written for the wave kernel to read.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* cost, unsigned* order, int n_tiles, float split_frac,
+                                                          unsigned long long* split_out, unsigned long long* lane_counter) {
   __shared__ unsigned hist[kCostBins];
   __shared__ unsigned offs[kCostBins];
   for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) hist[i] = 0;
@@ -1556,9 +1568,25 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* cost, 
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned run = 0;
+    unsigned long long total_cost = 0;
     for (int b = kCostBins - 1; b >= 0; --b) {  // descending cost
       offs[b] = run;
       run += hist[b];
+      total_cost += (unsigned long long)hist[b] * (unsigned long long)(b > 0 ? b : 1);
+    }
+    if (split_out != nullptr) {
+      const unsigned long long target = (unsigned long long)((double)split_frac * (double)total_cost);
+      unsigned long long cum = 0;
+      unsigned k = 0;
+      for (int b = kCostBins - 1; b >= 0 && cum < target; --b) {
+        const unsigned long long c = (unsigned long long)(b > 0 ? b : 1);
+        const unsigned long long want = (target - cum + c - 1) / c;  // tiles of this cost still needed
+        const unsigned take = want < hist[b] ? (unsigned)want : hist[b];
+        k += take;
+        cum += c * take;
+      }
+      *split_out = k;
+      *lane_counter = (unsigned long long)k * kTilePixels;
     }
   }
   __syncthreads();
@@ -1705,8 +1733,9 @@ hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream) {
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles);
+hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, float split_frac, unsigned long long* split_out,
+                             unsigned long long* lane_counter, hipStream_t stream) {
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles, split_frac, split_out, lane_counter);
   return hipGetLastError();
 }
 

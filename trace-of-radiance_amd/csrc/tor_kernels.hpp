@@ -72,6 +72,7 @@ struct KParams {
   const double* cam_dev;  // 24 float64, TorCamera layout (cameras.nim:15-22)
   // coop_pixel_kernel (one wave per pixel): number of cold slots of the flat layout and that number padded to 64
   int n_cold_slots, coop_slots;
+  const unsigned long long* split;  // split mode: number of cost-ordered tiles the wave kernel takes (device word), else null
   const double* coop_trips;  // 4 float64 per trip of 64 slots {kind, time0, time1 - time0, 0} (tor_scene.hpp)
 };
 
@@ -83,7 +84,8 @@ int coop_blocks_per_cu(const KParams& p, int arith);  // 0: the objects do not f
 hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream);
 int integrate_fixed_lds_bytes(int blocks, int coop);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists)
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
-hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, hipStream_t stream);
+hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, float split_frac, unsigned long long* split_out,
+                             unsigned long long* lane_counter, hipStream_t stream);
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
