@@ -117,7 +117,8 @@ constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 
 // cooperative resolve (F32 && BLOCKS variants): pair list and survivor list (64 carried over + 512 new per trip), the
 // per-ray closest hit {t bits, (original index, slot)}
 constexpr int kCoopList = 576;
-constexpr int coop_bytes(int blocks) { return (blocks ? 2 : 1) * kCoopList * 4 + 64 * 2 * 8; }  // (no pair list without boxes)
+// (+ the paths' attenuation: 3 x 64 float64 -- touched once per bounce, so it lives in LDS, not in 6 of the 168 registers)
+constexpr int coop_bytes(int blocks) { return (blocks ? 2 : 1) * kCoopList * 4 + 64 * 2 * 8 + 3 * 64 * 8; }  // (no pair list without boxes)
 constexpr int wave_lds_bytes(int blocks, int coop = 0) {
   return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) : 0);
 }
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned long long* coop_w = coop_t + 64;                                        // [64] (original index << 32) | cold slot at that t
   unsigned* coop_surv = reinterpret_cast<unsigned*>(coop_w + 64);                  // [kCoopList] lane | cold slot << 6
   unsigned* coop_pair = coop_surv + kCoopList;                                     // [kCoopList] lane | block << 6 (BLOCKS variants only)
+  double* coop_att = reinterpret_cast<double*>(coop_pair + kCoopList) + lane;      // [3][64] the paths' attenuation (coop variants)
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
@@ -228,6 +230,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   bool active = false;     // owns a live path
   bool have_item = false;  // owns a work item whose camera ray has not been generated yet
   V3 o = v3(0, 0, 0), d = v3(0, 0, 1), att = v3(1, 1, 1);
+  // attenuation of the lane's path (render.nim:22,35): a register triple, or -- cooperative variants, which are short
+  // of registers -- three LDS words per lane
+  constexpr bool kAttInLds = coop_variant(F32, BLOCKS);
+  auto get_att = [&]() { return kAttInLds ? v3(coop_att[0], coop_att[64], coop_att[128]) : att; };
+  auto set_att = [&](V3 v) {
+    if (kAttInLds) { coop_att[0] = v.x; coop_att[64] = v.y; coop_att[128] = v.z; }
+    else att = v;
+  };
   double time = 0.0;
   Rng rng{0, 0, 0, 0};
   int depth = 0;
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       o = r.origin;
       d = r.direction;
       time = r.time;
-      att = v3(1.0, 1.0, 1.0);  // render.nim:22
+      set_att(v3(1.0, 1.0, 1.0));  // render.nim:22
       depth = 0;
       active = true;
     }
@@ -734,7 +744,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             if (mine) {
               auto filter_block = [&](auto blk, auto ST) {
                 constexpr int st = decltype(ST)::value;
-#pragma unroll
+                // two pairs at a time: with all four in flight the 168-register variants spill inside the bounce loop
+                // (and every spill store shows up as HBM write traffic: 20 GB per C2 frame, measured)
+#pragma unroll 2
                 for (int j = 0; j < kBlock / 2; ++j) {
                   auto rr = blk + st * j;
                   const f2v c0x = {rr[0], rr[1]}, c0y = {rr[2], rr[3]}, c0z = {rr[4], rr[5]};
@@ -1123,7 +1135,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       // copy, in front of the branches, serves all of them (same operations on the same ray: same bits)
       const V3 ud_ray = unit_vector(d);
       if (best_idx < 0) {
-        radiance = sky_unit(ud_ray, att);  // render.nim:41-45
+        radiance = sky_unit(ud_ray, get_att());  // render.nim:41-45
         ended = true;
       } else {
         const double* c = p.cold + (size_t)best_idx * 16;
@@ -1142,7 +1154,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         if (mat == kLambertian) {  // materials.nim:24-30
           d = n + random_unit_vector(rng);
           o = hp;
-          att = mul_att(att, albedo);  // render.nim:35
+          set_att(mul_att(get_att(), albedo));  // render.nim:35
         } else if (mat == kMetal) {  // materials.nim:39-47
           const V3 reflected = reflect(ud_ray, n);
           const V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
@@ -1150,7 +1162,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           d = nd;
           time = 0.0;  // rays.nim:19 default
           if (dot(nd, n) > 0.0) {
-            att = mul_att(att, albedo);
+            set_att(mul_att(get_att(), albedo));
           } else {
             ended = true;  // render.nim:38: absorbed -> black
           }
@@ -1171,7 +1183,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           o = hp;
           d = nd;
           time = 0.0;
-          att = mul_att(att, v3(1.0, 1.0, 1.0));
+          set_att(mul_att(get_att(), v3(1.0, 1.0, 1.0)));
         }
         if (!ended) {
           depth += 1;
