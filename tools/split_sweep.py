@@ -22,7 +22,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" | ".join(out), flush=True)
 else:
     sizes = sys.argv[1:] or ["216x384x100", "288x512x100", "432x768x100", "720x1280x100"]
-    for frac in ("0", "-1", "0.3", "0.45"):
+    for frac in (os.environ.get("FRACS", "0,-1,0.3,0.45").split(",")):
         env = dict(os.environ, TOR_SPLIT_FRAC=frac)
         r = subprocess.run([sys.executable, __file__, "child"] + sizes, capture_output=True, text=True, env=env, timeout=300)
         print(f"frac {frac}: " + (r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]), flush=True)

@@ -431,14 +431,18 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   tor::KParams p{};
   // Small SEED_PIXEL frames: one wave per pixel (coop_pixel_kernel) -- the lane-per-pixel kernel would be bound by
   // the latency of the longest pixel chain.  Same canvas bit for bit; needs only the float64 flat layout.
-  // Split fraction: the wave-per-pixel kernel saturates at ~285 Msamples/s, the lane kernel (with both exact
-  // accelerations) has a latency floor of ~0.18 ms per sample-per-pixel; the two finish together when the wave
-  // kernel takes about 50 000 pixels' worth of the cost, at most 45 % (measured: tools/split_sweep.py).
+  // Split fraction (measured: tools/split_sweep.py): the wave-per-pixel kernel saturates at ~285 Msamples/s, the
+  // lane kernel (with both exact accelerations) is bound by its longest chains; up to ~110 k pixels the two finish
+  // together with 45 % of the probed cost in the wave kernel, beyond that the best share shrinks like 20 000 / pixels
+  // (0.04 at 518 k, 0.02 at 922 k pixels: only the glass-sphere tiles), and from ~1.2 M pixels on the lane kernel is
+  // throughput bound and keeps everything.
   float split_frac = ctx->split_frac;
   if (split_frac < 0.0f) {
-    split_frac = (o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) ? 50000.0f / (float)npix : 0.0f;
-    if (split_frac > 0.45f) split_frac = 0.45f;
-    if (split_frac < 0.08f) split_frac = 0.0f;
+    split_frac = 0.0f;
+    if (o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) && npix <= 1200000) {
+      split_frac = (npix <= 114688) ? 0.45f : 20000.0f / (float)npix;
+      if (split_frac < 0.02f) split_frac = 0.02f;
+    }
   }
   const bool split_applies = o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
                              npix >= ctx->split_min_pixels && npix <= ctx->split_max_pixels && !ctx->collect_stats && ctx->n_objects > 0;

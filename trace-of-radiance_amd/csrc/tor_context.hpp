@@ -150,7 +150,7 @@ struct TorContext {
   // tiles that carry split_frac of the probed cost go to the wave-per-pixel kernel on stream2, the lane kernel takes
   // the rest concurrently.  TOR_SPLIT_FRAC (0 = off), TOR_SPLIT_MIN_PIXELS, TOR_SPLIT_MAX_PIXELS.
   float split_frac = -1.0f;  // < 0: automatic (tor_render_device), 0: off
-  long long split_min_pixels = 16384, split_max_pixels = 1048576;
+  long long split_min_pixels = 16384, split_max_pixels = 100000000;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork[kRing] = {}, ev_join[kRing] = {};
 };
