@@ -35,7 +35,15 @@
 //     spatial blocks of 8 objects instead of the objects; the deferred pass expands, per lane, only
 //     the blocks whose box the ray can touch (compact records, staged in LDS when they fit).
 //
-//   tile_order_kernel  counting sort of the SEED_PIXEL tiles by probed cost (LPT schedule)
+//     TOR_ACCEL_BLOCKS | TOR_ACCEL_F32 variants resolve their candidates COOPERATIVELY: the wave pools the (ray, block)
+//     pairs and (ray, object) survivors of its 64 rays in LDS lists and works through them 64 at a time -- every
+//     lane busy, the owners' rays travel over ds_bpermute, closest hits are merged with LDS atomics (section
+//     "cooperative resolve" below).
+//
+//   coop_pixel_kernel  TOR_SEED_PIXEL, one WAVE per pixel chain: whole small frames, or -- split mode -- the most
+//                      expensive tiles of a mid-size frame while integrate_kernel renders the rest
+//   tile_order_kernel  counting sort of the SEED_PIXEL tiles by probed cost (LPT schedule) + the split point
+//   gather_rows_kernel multi-GPU assembly: rank-major row shards -> frame in image order
 //   finalize_kernel    canvas.nim:47-54 (draw): pow(sum * 1/spp, 1/gamma)
 //   quantize_kernel    io/ppm.nim:15-16
 //
@@ -1016,55 +1024,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   exact_hit(cx, cy, cz, blk[hs * j + 3], (unsigned)p.spatial_base + blk_id * kBlock + (unsigned)j, f);
                 }
               };
-              // the same through the float32 pre-filter: 4 pair records of ST floats (tor_filter32.hpp)
-              auto expand32 = [&](auto blk, auto ST, unsigned blk_id) {
-                constexpr int st = decltype(ST)::value;
-                unsigned m8 = 0;
-                // two pairs at a time: with all four in flight the 168-register variants spill inside the bounce loop
-#pragma unroll 2
-                for (int j = 0; j < kBlock / 2; ++j) {
-                  auto r = blk + st * j;
-                  const f2v c0x = {r[0], r[1]}, c0y = {r[2], r[3]}, c0z = {r[4], r[5]};
-                  f2v ocx, ocy, ocz;
-                  if (st == 16) {
-                    ocx = oc_moving32(r32.ox, c0x, (f2v){r[10], r[11]}, sp32.nf);
-                    ocy = oc_moving32(r32.oy, c0y, (f2v){r[12], r[13]}, sp32.nf);
-                    ocz = oc_moving32(r32.oz, c0z, (f2v){r[14], r[15]}, sp32.nf);
-                  } else {
-                    ocx = oc_static32(r32.ox, c0x);
-                    ocy = (st == 12) ? oc_moving32(r32.oy, c0y, (f2v){r[10], r[11]}, sp32.nf) : oc_static32(r32.oy, c0y);
-                    ocz = oc_static32(r32.oz, c0z);
-                  }
-                  m8 = filter_pair32(r32, sp32, ocx, ocy, ocz, (f2v){r[6], r[7]}, (f2v){r[8], r[9]}, m8);
-                }
-                m8 |= sp32.wild;
-                while (m8 != 0) {
-                  const int bb = 31 - __builtin_clz(m8);
-                  m8 &= ~(1u << bb);
-                  exact_cold((unsigned)p.spatial_base + blk_id * kBlock + (unsigned)(7 - bb));
-                }
-              };
               using S8 = std::integral_constant<int, 8>;
               using S4 = std::integral_constant<int, 4>;
-              using T10 = std::integral_constant<int, 10>;
-              using T12 = std::integral_constant<int, 12>;
-              using T16 = std::integral_constant<int, 16>;
+              // (float32 block records belong to the cooperative resolve above; this per-lane path serves F32 = 0)
               auto expand_block = [&](unsigned blk_id) {
                 if (stats_on) atomicAdd(&prof_lds[kStCand], (unsigned long long)kBlock);
-                if constexpr (F32 != 0) {
-                  // (the host pairs the float32 kernel variant with float32 block records, or with no blocks at all)
-                  const size_t off = (size_t)blk_id * (size_t)p.shot32_block_stride;
-                  if (p.shot32_lds_floats > 0) {
-                    if (p.shot32_stride == 12) expand32(shot32_lds + off, T12{}, blk_id);
-                    else if (p.shot32_stride == 10) expand32(shot32_lds + off, T10{}, blk_id);
-                    else expand32(shot32_lds + off, T16{}, blk_id);
-                  } else {
-                    const gfptr g32 = (gfptr)(uintptr_t)p.shot32;
-                    if (p.shot32_stride == 12) expand32(g32 + off, T12{}, blk_id);
-                    else if (p.shot32_stride == 10) expand32(g32 + off, T10{}, blk_id);
-                    else expand32(g32 + off, T16{}, blk_id);
-                  }
-                } else if (p.shot_stride == 8) {  // float64 compact records
+                if (p.shot_stride == 8) {  // float64 compact records
                   if (staged) expand(shot_lds + (size_t)blk_id * (8 * kBlock), S8{}, blk_id);            // ds_read
                   else expand((gdptr)(uintptr_t)p.shot + (size_t)blk_id * (8 * kBlock), S8{}, blk_id);  // global_load
                 } else {
@@ -1077,17 +1042,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               } else {
                 // super box `rec`: slab-test its 8 block boxes, descend into the ones the ray can touch
                 unsigned mc = 0;
-                if constexpr (F32 != 0) {
-                  auto child32 = [&](auto cb) {
-#pragma unroll 4
-                    for (int j = 0; j < kBlock; ++j)
-                      mc = (mc << 1) | slab_bit32(b32, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
-                                                  (f2v){cb[8 * j + 4], cb[8 * j + 5]});
-                  };
-                  if (p.bnd32_lds_floats > 0) child32(bnd32_lds + (size_t)rec * (8 * kBlock));
-                  else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
-                  mc |= r32.wild;
-                } else {
+                {
                 const gdptr cb = (gdptr)(uintptr_t)p.bnd + (size_t)rec * (8 * kBlock);
                 const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
 #pragma unroll
