@@ -31,3 +31,23 @@ def test_shard_plan_matches_c_abi(tor):
         assert sorted(seen.tolist()) == list(range(nrows))
         for k in range(world):
             assert plan.rows_of(k).tolist() == tor.shard_rows(nrows, tile, k, world).tolist()
+
+
+def test_gather_mapping_inverts_shard_rows(tor):
+    """The de-interleave step of the multi-GPU assembly (gather_rows_kernel, csrc/tor_kernels.hip) uses
+    row -> (shard = tile mod N, local row = (tile div N) * row_tile + row mod row_tile) with tile = row div row_tile.
+    It must be the inverse of tor_shard_rows for ragged splits too (row counts N does not divide, partial last tiles)."""
+    import numpy as np
+    for nrows in (2, 37, 216, 1080):
+        for n in (1, 2, 3, 5, 8, 16):
+            for tile in (1, 4, 7, 64):
+                owner = np.full(nrows, -1)
+                local = np.full(nrows, -1)
+                for k in range(n):
+                    rows = tor.shard_rows(nrows, tile, k, n)
+                    assert np.all(np.diff(rows) > 0)
+                    owner[rows] = k
+                    local[rows] = np.arange(len(rows))
+                r = np.arange(nrows)
+                t = r // tile
+                assert np.array_equal(owner, t % n) and np.array_equal(local, (t // n) * tile + r % tile), (nrows, n, tile)
