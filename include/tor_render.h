@@ -326,6 +326,10 @@ TOR_API int tor_last_stats(TorContext* ctx, TorStats* out);
  * refill + camera ray, object loop, exact resolve | shade, deposit, total}.
  * Returns the number of waves copied (<= cap_waves) or < 0. */
 TOR_API int tor_last_wave_log(TorContext* ctx, uint64_t* out, int64_t cap_waves);
+/* Debug: the cost probe of the last TOR_SEED_PIXEL launch (it runs from 32 spp on): closest-hit queries per pixel over the
+ * probe's samples (2 per pixel; per-sample streams, so only statistically what the frame's samples do), in the shard's
+ * local pixel order.  Returns the number of pixels copied (<= cap_pixels) or < 0 (no probe ran). */
+TOR_API int64_t tor_last_pixel_cost(TorContext* ctx, uint32_t* out, int64_t cap_pixels);
 
 /* ------------------------------------------------------------------------------------ */
 /* Host-side mirrors of the reference constructors on either side of the path            */

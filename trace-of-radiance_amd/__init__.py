@@ -131,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_slab32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
-    "tor_context_scene_counters", "tor_render_ptr",
+    "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost",
 ]
 
 _lib = None
@@ -205,6 +205,8 @@ def lib():
     L.tor_context_set_stats.argtypes = [C.c_void_p, C.c_int32]
     L.tor_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.tor_last_wave_log.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
+    L.tor_last_pixel_cost.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64]
+    L.tor_last_pixel_cost.restype = C.c_int64
     L.tor_camera_init.argtypes = [C.POINTER(Camera), C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Vec3)] + \
                                  [C.c_double] * 6
     L.tor_random_scene.argtypes = [C.c_uint64, C.POINTER(HittableVariant), C.c_int64]
@@ -571,6 +573,14 @@ class Context:
         n = C.c_int32(0)
         _check(lib().tor_kernel_ms_mean(self._h, last_n, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def last_pixel_cost(self, n_pixels: int) -> np.ndarray:
+        """Per-pixel closest-hit query counts of the last launch's cost probe (debug; tor_last_pixel_cost)."""
+        buf = np.zeros(n_pixels, dtype=np.uint32)
+        n = lib().tor_last_pixel_cost(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint32)), n_pixels)
+        if n < 0:
+            _check(int(n))
+        return buf[:n]
 
     def last_wave_log(self, cap_waves: int = 16384) -> np.ndarray:
         buf = np.zeros((cap_waves, 8), dtype=np.uint64)

@@ -272,12 +272,18 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
   if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
   if (const char* c = std::getenv("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
+  if (const char* c = std::getenv("TOR_BACK_SLOT")) ctx->back_slot = std::atoi(c);
+  if (const char* c = std::getenv("TOR_BACK_ACCEL")) ctx->back_accel = std::atoi(c) != 0;
+  if (const char* c = std::getenv("TOR_PROBE_SPP")) ctx->probe_spp = std::atoi(c) > 0 ? std::atoi(c) : 2;
+  if (const char* c = std::getenv("TOR_HOT_FRAC")) ctx->hot_frac = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_TAIL_FRAC")) ctx->tail_frac = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_PRIO_SHIFT")) ctx->prio_shift = std::atoi(c);
   if (const char* c = std::getenv("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
   if (const char* c = std::getenv("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
     for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
-  e = ctx->counters.ensure(TorContext::kRing * 8 * sizeof(unsigned long long));
+  e = ctx->counters.ensure(TorContext::kRing * TorContext::kSlotWords * sizeof(unsigned long long));
   if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kRing * sizeof(TorCamera));
   for (int i = 0; i < TorContext::kRing && e == hipSuccess; ++i) {
     e = hipEventCreate(&ctx->ev_start[i]);
@@ -419,8 +425,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   // launch must be done
   const int slot = (int)(ctx->launches % TorContext::kRing);
   if (ctx->launches >= TorContext::kRing) HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
-  unsigned long long* const slot_counters = (unsigned long long*)ctx->counters.ptr + (size_t)slot * 8;
-  HIP_TRY(hipMemsetAsync(slot_counters, 0, 8 * sizeof(unsigned long long), stream));
+  unsigned long long* const slot_counters = (unsigned long long*)ctx->counters.ptr + (size_t)slot * TorContext::kSlotWords;
+  HIP_TRY(hipMemsetAsync(slot_counters, 0, TorContext::kSlotWords * sizeof(unsigned long long), stream));
   if (max_depth <= 0 || ctx->n_objects < 0) {
     // render.nim:25: the bounce loop does not run -> every sample is black -> pow(0, g) = 0
     HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n_values * 8, stream));
@@ -583,7 +589,9 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   long long waves;
   p.n_pixels = (unsigned)npix;
   p.order = nullptr;
-  p.tile_cost = nullptr;
+  p.pixel_cost = nullptr;
+  ctx->last_probe_pixels = 0;
+  p.sched = nullptr;
   const long long n_tiles = (npix + tor::kTilePixelsHost - 1) / tor::kTilePixelsHost;
   if (o.seeding == TOR_SEED_PIXEL) {
     p.total_work = (unsigned long long)n_tiles * tor::kTilePixelsHost;  // tiles of 64 pixels
@@ -625,18 +633,20 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     // per tile, it never touches the canvas) + a counting sort; ~2/spp of extra work.
     DeviceBuffer& tile_cost = ctx->tile_cost[slot];
     DeviceBuffer& tile_order = ctx->tile_order[slot];
-    HIP_TRY(tile_cost.ensure((size_t)n_tiles * 4));
+    // per-pixel query counts of the probe, then per tile: sort key, probed work
+    HIP_TRY(tile_cost.ensure(((size_t)npix + 2 * (size_t)n_tiles) * 4));
     HIP_TRY(tile_order.ensure((size_t)n_tiles * 4));
-    HIP_TRY(hipMemsetAsync(tile_cost.ptr, 0, (size_t)n_tiles * 4, stream));
+    HIP_TRY(hipMemsetAsync(tile_cost.ptr, 0, (size_t)npix * 4, stream));
     tor::KParams pp = p;
-    pp.spp = 2;
-    pp.total_work = (unsigned long long)npix * 2ull;
+    pp.spp = ctx->probe_spp;
+    pp.total_work = (unsigned long long)npix * (unsigned long long)ctx->probe_spp;
+    ctx->last_probe_pixels = npix;
     pp.chunk = 256;
     pp.work_counter = slot_counters + 5;
     pp.stats = nullptr;
     pp.wave_log = nullptr;
     pp.out = nullptr;
-    pp.tile_cost = (unsigned*)tile_cost.ptr;
+    pp.pixel_cost = (unsigned*)tile_cost.ptr;
     long long pw = (long long)((pp.total_work + 63) / 64);
     const long long pres = (long long)ctx->num_cus * 3 * (tor::kThreads / 64);
     if (pw > pres) pw = pres;
@@ -664,8 +674,19 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       wk.wave_log = nullptr;
       split = tor::coop_blocks_per_cu(wk, o.arith) > 0;
     }
-    HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned*)tile_order.ptr, (int)n_tiles, split ? split_frac : 0.0f,
-                                   split ? slot_counters + 6 : nullptr, split ? slot_counters : nullptr, stream));
+    unsigned* const tile_key = (unsigned*)tile_cost.ptr + npix;
+    // schedule of the lane kernel (tor_kernels.hip): two regions where some wave slot is slow enough to need it, and the
+    // hot chains: a pixel chain is hot when it needs more than hot_frac of the iterations an average wave runs in this frame
+    //   average = total probed queries * spp / probe_spp / lanes
+    const bool two_regions = ctx->back_slot > 0 && ctx->back_slot < waves_per_simd && ctx->tail_frac > 0.0f && (o.accel == 0 || ctx->back_accel);
+    p.back_slot = two_regions ? ctx->back_slot : 1 << 20;
+    p.prio_shift = ctx->prio_shift;
+    p.sched = slot_counters + 8;
+    HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned)npix, tile_key, tile_key + n_tiles, (unsigned*)tile_order.ptr,
+                                   (int)n_tiles, split ? split_frac : 0.0f, split ? slot_counters + 6 : nullptr,
+                                   split ? slot_counters : nullptr, two_regions ? ctx->tail_frac : 0.0f,
+                                   ctx->hot_frac > 0.0f ? ctx->hot_frac * (float)spp / (float)ctx->probe_spp / (float)(resident_waves * 64) : -1.0f,
+                                   p.sched, stream));
     p.order = (const unsigned*)tile_order.ptr;
     if (split) {
       if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -834,13 +855,23 @@ int tor_last_wave_log(TorContext* ctx, uint64_t* out, int64_t cap_waves) {
   return (int)n;
 }
 
+int64_t tor_last_pixel_cost(TorContext* ctx, uint32_t* out, int64_t cap_pixels) {
+  if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_pixel_cost: NULL argument");
+  if (ctx->last_probe_pixels <= 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_pixel_cost: the last launch ran no cost probe");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t n = ctx->last_probe_pixels < cap_pixels ? ctx->last_probe_pixels : cap_pixels;
+  HIP_TRY(hipMemcpy(out, ctx->tile_cost[ctx->last_slot].ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return n;
+}
+
 int tor_last_stats(TorContext* ctx, TorStats* out) {
   if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: NULL argument");
   if (!ctx->collect_stats) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: stats not enabled");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipDeviceSynchronize());
   unsigned long long h[8];
-  HIP_TRY(hipMemcpy(h, (unsigned long long*)ctx->counters.ptr + (size_t)ctx->last_slot * 8, sizeof h, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(h, (unsigned long long*)ctx->counters.ptr + (size_t)ctx->last_slot * TorContext::kSlotWords, sizeof h, hipMemcpyDeviceToHost));
   out->hit_queries = h[1];
   out->object_tests = h[1] * (uint64_t)ctx->n_objects;
   out->candidates = h[2];

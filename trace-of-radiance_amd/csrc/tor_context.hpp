@@ -89,7 +89,8 @@ struct RcclComm;  // tor_multi.cpp
 }  // namespace tor
 
 struct TorContext {
-  static constexpr int kRing = 64;  // per-launch slots: events, camera, bounds, counters, tile schedule
+  static constexpr int kRing = 64;
+  static constexpr int kSlotWords = 16;  // 64-bit words per ring slot: work counter, 4 statistics, probe counter, split, wave-kernel counter, schedule (2)  // per-launch slots: events, camera, bounds, counters, tile schedule
   int device = 0;
   int num_cus = 0;
   // ---- scene: a byte copy of the caller's list (cache key + source of the lazily built layouts) ----
@@ -111,6 +112,13 @@ struct TorContext {
   // ---- per-launch state ----
   tor::DeviceBuffer counters;                      // kRing x 8 u64: [0] work counter, [1..4] stats, [5] probe counter
   tor::DeviceBuffer tile_cost[kRing], tile_order[kRing];  // SEED_PIXEL cost-ordered schedule
+  int back_slot = 2;    // SEED_PIXEL: wave slots >= this take tiles from the cheap end (0 = none; TOR_BACK_SLOT)
+  float hot_frac = 0.4f;   // a pixel chain is hot (arbiter priority 3) from this share of an average wave's iterations on (TOR_HOT_FRAC; 0 = off)
+  float tail_frac = 0.2f;  // share of the lane kernel's probed work in region B of its schedule (TOR_TAIL_FRAC)
+  int probe_spp = 2;            // samples per pixel of the cost probe (TOR_PROBE_SPP: debugging the schedule)
+  int64_t last_probe_pixels = 0;
+  bool back_accel = false;  // two regions with an exact acceleration too (TOR_BACK_ACCEL; measured slower: the slots differ less there)
+  int prio_shift = 16;  // SEED_PIXEL: arbiter-priority rotation period, log2 shader-clock ticks (tor_kernels.hip; 0 = off; TOR_PRIO_SHIFT)
   tor::DeviceBuffer wave_log;                      // debug: 8 x u64 per wave (only with stats enabled)
   tor::DeviceBuffer cam_ring;                      // kRing x TorCamera
   TorCamera cam_host[kRing];                       // host staging must outlive the asynchronous copies
@@ -140,7 +148,7 @@ struct TorContext {
   //           wave that holds one must get good service; with an exact acceleration the iteration is short
   //           enough that 3 workgroups/CU win (C2: f32 1768 -> 1900, blocks 1625 -> 1790, both 2133 -> 2350)
   // Overridable for experiments: TOR_WAVES_PER_SIMD (2|3), TOR_BLOCKS_PER_CU.
-  int max_blocks_per_cu[2][2] = {{2, 3}, {3, 3}};  // [seeding][any TOR_ACCEL_* bit set]
+  int max_blocks_per_cu[2][2] = {{3, 3}, {3, 3}};  // [seeding][any TOR_ACCEL_* bit set]
   int lpt_min_spp = 32;    // SEED_PIXEL: probe + cost-ordered tiles from this many spp on (0 = never)
   int waves_override = 0;  // TOR_WAVES_PER_SIMD (2|3): force a register-budget variant of the kernel
   // SEED_PIXEL frames of at most this many (local) pixels run coop_pixel_kernel (one wave per pixel: the frame is

@@ -259,6 +259,15 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned long long w_next = 0, w_end = 0;
   unsigned cur_pl = 0, cur_s = 0;
   unsigned next_chunk = p.chunk;
+  const unsigned prio_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_ID.wave_id: the wave's slot in its SIMD
+  unsigned prio_now = 0;
+  // SEED_PIXEL tile schedule (see the fetch below): waves of the slow slots skip region A
+  const bool from_back = SEEDING == 0 && p.sched != nullptr && prio_slot >= (unsigned)p.back_slot;
+  const unsigned long long a_end = (SEEDING == 0 && p.sched != nullptr) ? p.sched[0] : p.total_work;
+  // a pixel chain is HOT when, extrapolated from its samples so far, it needs more than hot_iters bounce iterations
+  const unsigned hot_iters = (SEEDING == 0 && p.sched != nullptr) ? (unsigned)p.sched[2] : 0u;
+  bool a_done = from_back;
+  unsigned pix_iters = 0;  // bounce iterations the lane has spent on its current pixel
   bool exhausted = false;
   // statistics (tor_last_stats / wave log) live in LDS and are touched only when they were asked for: the
   // kernel is short of scalar registers, counters that are always live would be paid for on every launch
@@ -297,8 +306,42 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         unsigned grab = (SEEDING == 0) ? p.chunk : next_chunk;
         if (SEEDING != 0 && grab >= (unsigned)p.spp) grab = grab / (unsigned)p.spp * (unsigned)p.spp;
         unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(p.work_counter, (unsigned long long)grab);
-        base = bcast_first_u64(__shfl(base, leader));
+        if (SEEDING == 0) {
+          // Two regions of the chain-length-descending tile order (tile_order_kernel): A = [.., a_end) holds the long
+          // chains, B = [a_end, total) the cheap end.  Waves in the fast hardware slots work through A and then B;
+          // waves in the slow slots take from B only.  Why: the instruction arbiter serves the oldest wave of a SIMD
+          // first -- 39 / 64 / 177 us per bounce iteration in wave slots 0 / 1 / 2 with three waves per SIMD -- and a
+          // pixel is one sequential chain of spp samples: the longest chains (glass, ~27 bounces per sample) need about
+          // as many iterations as an average wave runs in the whole frame, so they finish in time only in a fast slot;
+          // in slot 2 they end the frame alone (measured: counter dry at 172 ms, last wave at 200-225 ms).  Equalising
+          // the service with s_setprio makes it worse (64 us for everybody: every long chain is late).  Everybody ends
+          // in B, cheapest tiles last.
+          if (!a_done) {
+            if (lane == leader) base = atomicAdd(p.work_counter, (unsigned long long)kTilePixels);
+            base = bcast_first_u64(__shfl(base, leader));
+            if (base >= a_end) a_done = true;
+          }
+          if (a_done) {
+            base = p.total_work;
+            bool take = p.sched != nullptr;
+            if (take && from_back) {
+              // a slow wave stops taking pixels once the fast waves have finished region A and arrive in B: even the
+              // cheapest pixel (sky, spp iterations) takes it ~10 % of the frame; it drains at the top priority and
+              // leaves its issue slots to the others
+              unsigned long long front = 0;
+              if (lane == leader) front = __hip_atomic_load(p.work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              front = bcast_first_u64(__shfl(front, leader));
+              take = front < a_end;
+            }
+            if (take) {
+              if (lane == leader) base = atomicAdd(p.sched + 1, (unsigned long long)kTilePixels);
+              base = bcast_first_u64(__shfl(base, leader));
+            }
+          }
+        } else {
+          if (lane == leader) base = atomicAdd(p.work_counter, (unsigned long long)grab);
+          base = bcast_first_u64(__shfl(base, leader));
+        }
         if (base >= p.total_work) {
           exhausted = true;
           if (prof && lane == 0) { prof_lds[kLogExhausted] = wall_clock64(); prof_lds[kLogItersAtExhaustion] = prof_lds[kStIters]; }
@@ -351,7 +394,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           row = (int)((tile * (unsigned)p.shard_count + (unsigned)p.shard_index) * (unsigned)p.row_tile + within);
           pix = (int)pl;
           have_item = true;
-          if (SEEDING == 0) seed2(rng, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);  // render.nim:59-60
+          if (SEEDING == 0) {
+            seed2(rng, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);  // render.nim:59-60
+            pix_iters = 0;
+          }
         }
         w_next += take;
         if (SEEDING == 0) {
@@ -384,6 +430,38 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     if (active_mask == 0) {
       if (exhausted) break;
       continue;
+    }
+    if (SEEDING == 0 && p.sched != nullptr) {
+      // Arbiter priority of the wave (s_setprio; the levels beat the age order):
+      //  3  while one of its lanes works on a HOT pixel -- a chain so long (glass: up to ~36 queries per sample against
+      //     a mean of 2.6) that even an average slot would finish it after everybody else.  Judged on the lane's own
+      //     record: iterations so far, extrapolated to spp samples, against hot_iters (a share of what an average wave
+      //     runs in the whole frame, from the probe's total); a few dozen pixels per frame;
+      //  1-2 fast slots, taking turns (level = 1 + (slot + clock phase) mod 2, the phase from the shader clock they
+      //     share) so that both get the same service;
+      //  0  slow slots (region B only).
+      if (active) pix_iters += 1;
+      const bool lane_hot = active && hot_iters != 0 && pix_iters >= 64u &&
+                            (unsigned long long)pix_iters * (unsigned)p.spp >= (unsigned long long)hot_iters * (unsigned)(s + 1);
+      const bool wave_hot = ballot64(lane_hot) != 0;
+      unsigned level = 0;
+      if (wave_hot || (from_back && exhausted)) {
+        level = 3;
+      } else if (!from_back) {
+        level = 1;
+        if (p.prio_shift > 0) {
+          const unsigned n_front = ((unsigned)p.back_slot < (unsigned)WAVES_PER_SIMD) ? (unsigned)p.back_slot : (unsigned)WAVES_PER_SIMD;
+          const unsigned phase = (unsigned)(__builtin_readcyclecounter() >> p.prio_shift);
+          level = 1u + (prio_slot + phase) % (n_front < 2u ? n_front : 2u);
+        }
+      }
+      if (level != prio_now) {
+        prio_now = level;
+        if (level == 0) __builtin_amdgcn_s_setprio(0);
+        else if (level == 1) __builtin_amdgcn_s_setprio(1);
+        else if (level == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
     }
     if (stats_on && lane == 0) {
       prof_lds[kStIters] += 1;
@@ -1150,7 +1228,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         active = false;
         if (stats_on) atomicAdd(&prof_lds[kStSamples], 1ull);
         if (kProbe) {
-          atomicAdd(p.tile_cost + ((unsigned)pix / kTilePixels), (unsigned)path_q);
+          atomicAdd(p.pixel_cost + (unsigned)pix, (unsigned)path_q);
           path_q = 0;
         }
         if (SEEDING == 0) {
@@ -1518,48 +1596,100 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
 // (longest-processing-time-first: a pixel is a sequential chain of spp samples, so the expensive
 // chains must start at t = 0).  One workgroup; the order of equal-cost tiles is irrelevant (the
 // schedule never changes a pixel's value).
-constexpr int kCostBins = 8192;
-// With split_frac > 0 it also cuts the cost-descending list: the first K tiles carry split_frac of the probed cost
-// (the expensive pixel chains: they go to coop_pixel_kernel, one wave per pixel), the rest stays with the lane
-// kernel, whose work counter is therefore started at tile K.  K is written for the wave kernel to read.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* cost, unsigned* order, int n_tiles, float split_frac,
-                                                          unsigned long long* split_out, unsigned long long* lane_counter) {
+constexpr int kCostBins = 4096;
+
+// The probe counts closest-hit queries per PIXEL (2 samples).  A tile's sort key is led by its longest pixel chain --
+// lanes pull pixels one by one, so the chain, not the tile's sum, is what has to start early (a tile on the rim of a
+// glass sphere has a few 27-bounce pixels among sky: by its sum it would start mid-frame and its chains would end the
+// frame) -- with the tile's sum as the tie-breaker; the sum itself is kept for the work accounting of the cuts.
+__global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cost, unsigned n_pixels, int n_tiles, unsigned* key,
+                                                        unsigned* work) {
+  const int tile = (int)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64);
+  if (tile >= n_tiles) return;
+  const unsigned pl = (unsigned)tile * kTilePixels + (threadIdx.x & 63);
+  const unsigned c = pl < n_pixels ? pixel_cost[pl] : 0u;
+  unsigned mx = c, sum = c;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned om = (unsigned)__shfl_xor((int)mx, off), os = (unsigned)__shfl_xor((int)sum, off);
+    mx = om > mx ? om : mx;
+    sum += os;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned m = mx < 127u ? mx : 127u;        // 2 samples x max_depth 50 <= 100 (more only with a deeper max_depth)
+    const unsigned t = (sum >> 8) < 31u ? (sum >> 8) : 31u;
+    key[tile] = (m << 5) | t;
+    work[tile] = sum > 0 ? sum : 1u;
+  }
+}
+
+// Counting sort of the tiles by descending key (longest-processing-time-first: a pixel is a sequential chain of spp
+// samples, so the long chains must start at t = 0).  One workgroup; the order of equal-key tiles is irrelevant (the
+// schedule never changes a pixel's value).  Two cuts of the sorted list, both by probed work:
+//  * split_frac > 0: the first K tiles carry split_frac of the work (the longest chains: they go to coop_pixel_kernel,
+//    one wave per pixel); the lane kernel's counter is started at tile K, K is written for the wave kernel to read;
+//  * tail_frac: the last tiles, carrying tail_frac of the lane kernel's work, form region B of the lane kernel's
+//    schedule: sched[0] = first index of B, sched[1] = B's work counter (started there);
+//  * sched[2] = hot_chain x the probed total: the chain length (bounce iterations) from which a pixel is HOT (priority 3).
+__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, const unsigned* work, unsigned* order, int n_tiles,
+                                                          float split_frac, unsigned long long* split_out,
+                                                          unsigned long long* lane_counter, float tail_frac, float hot_chain,
+                                                          unsigned long long* sched) {
   __shared__ unsigned hist[kCostBins];
   __shared__ unsigned offs[kCostBins];
-  for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) hist[i] = 0;
+  __shared__ unsigned long long bin_work[kCostBins];
+  for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) { hist[i] = 0; bin_work[i] = 0; }
   __syncthreads();
   for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-    unsigned c = cost[i];
-    atomicAdd(&hist[c < (unsigned)kCostBins ? c : (unsigned)kCostBins - 1], 1u);
+    const unsigned b = key[i] < (unsigned)kCostBins ? key[i] : (unsigned)kCostBins - 1;
+    atomicAdd(&hist[b], 1u);
+    atomicAdd(&bin_work[b], (unsigned long long)work[i]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned run = 0;
-    unsigned long long total_cost = 0;
-    for (int b = kCostBins - 1; b >= 0; --b) {  // descending cost
+    unsigned long long total = 0;
+    for (int b = kCostBins - 1; b >= 0; --b) {  // descending key
       offs[b] = run;
       run += hist[b];
-      total_cost += (unsigned long long)hist[b] * (unsigned long long)(b > 0 ? b : 1);
+      total += bin_work[b];
     }
-    if (split_out != nullptr) {
-      const unsigned long long target = (unsigned long long)((double)split_frac * (double)total_cost);
+    // first k tiles of the order that carry `target` work (tiles of one bin count with the bin's mean)
+    auto tiles_for = [&](unsigned long long target) {
       unsigned long long cum = 0;
       unsigned k = 0;
       for (int b = kCostBins - 1; b >= 0 && cum < target; --b) {
-        const unsigned long long c = (unsigned long long)(b > 0 ? b : 1);
-        const unsigned long long want = (target - cum + c - 1) / c;  // tiles of this cost still needed
+        if (hist[b] == 0) continue;
+        const unsigned long long mean = (bin_work[b] + hist[b] - 1) / hist[b];
+        const unsigned long long want = (target - cum + mean - 1) / mean;
         const unsigned take = want < hist[b] ? (unsigned)want : hist[b];
         k += take;
-        cum += c * take;
+        cum += mean * take;
       }
-      *split_out = k;
-      *lane_counter = (unsigned long long)k * kTilePixels;
+      return k;
+    };
+    unsigned k_split = 0;
+    unsigned long long lane_work = total;
+    if (split_out != nullptr) {
+      const unsigned long long target = (unsigned long long)((double)split_frac * (double)total);
+      k_split = tiles_for(target);
+      *split_out = k_split;
+      *lane_counter = (unsigned long long)k_split * kTilePixels;
+      lane_work = total > target ? total - target : 0;
+    }
+    if (sched != nullptr) {
+      const unsigned long long front = total - (unsigned long long)((double)tail_frac * (double)lane_work);
+      unsigned k_tail = tiles_for(front);
+      if (k_tail < k_split) k_tail = k_split;
+      if (k_tail > (unsigned)n_tiles) k_tail = (unsigned)n_tiles;
+      sched[0] = (unsigned long long)k_tail * kTilePixels;
+      sched[1] = (unsigned long long)k_tail * kTilePixels;
+      // hot chains: hot_chain x the probed total, scaled by the host to bounce iterations of the frame
+      sched[2] = hot_chain > 0.0f ? (unsigned long long)(hot_chain * (float)total) + 1ull : 0ull;
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-    unsigned c = cost[i];
-    unsigned b = c < (unsigned)kCostBins ? c : (unsigned)kCostBins - 1;
+    const unsigned b = key[i] < (unsigned)kCostBins ? key[i] : (unsigned)kCostBins - 1;
     order[atomicAdd(&offs[b], 1u)] = (unsigned)i;
   }
 }
@@ -1700,9 +1830,12 @@ hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, float split_frac, unsigned long long* split_out,
-                             unsigned long long* lane_counter, hipStream_t stream) {
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles, split_frac, split_out, lane_counter);
+hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
+                             float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
+                             float hot_chain, unsigned long long* sched, hipStream_t stream) {
+  hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, pixel_cost, n_pixels, n_tiles, key, work);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned*)key, (const unsigned*)work, order, n_tiles, split_frac,
+                     split_out, lane_counter, tail_frac, hot_chain, sched);
   return hipGetLastError();
 }
 

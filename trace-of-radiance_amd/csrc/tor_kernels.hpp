@@ -63,7 +63,10 @@ struct KParams {
   unsigned n_waves; // waves launched
   unsigned n_pixels;  // local pixels (rows of this shard x ncols)
   const unsigned* order;  // SEED_PIXEL: nullable tile order (cost-descending), n_tiles entries
-  unsigned* tile_cost;    // probe launch: per-tile closest-hit query count
+  unsigned* pixel_cost;   // probe launch: per-pixel closest-hit query count (2 samples)
+  unsigned long long* sched;  // SEED_PIXEL + order: [0] first index of region B of the order, [1] region B's work counter, [2] hot chain length; else null
+  int back_slot;          // SEED_PIXEL: waves in hardware wave slots >= back_slot take tiles from region B only
+  int prio_shift;         // SEED_PIXEL: rotate the waves' arbiter priority every 2^prio_shift shader-clock ticks (0 = off)
   unsigned long long total_work;
   unsigned long long* work_counter;
   double* out;
@@ -84,8 +87,9 @@ int coop_blocks_per_cu(const KParams& p, int arith);  // 0: the objects do not f
 hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream);
 int integrate_fixed_lds_bytes(int blocks, int coop);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists)
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
-hipError_t launch_tile_order(const unsigned* cost, unsigned* order, int n_tiles, float split_frac, unsigned long long* split_out,
-                             unsigned long long* lane_counter, hipStream_t stream);
+hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
+                             float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
+                             float hot_chain, unsigned long long* sched, hipStream_t stream);
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
