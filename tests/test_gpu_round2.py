@@ -425,3 +425,57 @@ def test_split_mode_lane_and_wave_kernels_share_a_frame(tor, oracle, ref_scene, 
     tor.render(c, cam, scene.list(), 50)
     tor.render(b, cam, scene.list(), 50)
     assert np.array_equal(a.pixels, b.pixels)
+
+
+def test_pixel_schedule_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
+    """The TOR_SEED_PIXEL lane kernel's schedule (tiles ordered by their longest probed chain, two regions
+    of the order, slow wave slots retiring early, arbiter priorities) only decides WHO renders a pixel and WHEN.  A
+    frame large enough to occupy every hardware wave slot (> 3072 tiles, pixel count not a multiple of the tile) must
+    come out identical for every setting of the knobs -- including ones that push most of the work into region B,
+    make nearly every chain hot, or switch the machinery off -- and equal to the oracle."""
+    objs, _ = ref_scene
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    h, w, spp = 385, 515, 32
+    rows = np.array([0, 97, 200, 384])
+    want = np.stack([oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=1, arith=0, rows=(int(r), int(r) + 1)).pixels[r]
+                     for r in rows])
+    knobs = [
+        {},
+        {"TOR_TAIL_FRAC": "0.7", "TOR_HOT_FRAC": "0.02", "TOR_PRIO_SHIFT": "6"},
+        {"TOR_BACK_SLOT": "1", "TOR_TAIL_FRAC": "0.05"},
+        {"TOR_BACK_SLOT": "0", "TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0"},
+        {"TOR_BACK_ACCEL": "1", "TOR_TAIL_FRAC": "0.5"},
+        {"TOR_LPT_MIN_SPP": "0"},
+        {"TOR_BLOCKS_PER_CU": "2", "TOR_WAVES_PER_SIMD": "2"},
+    ]
+    names = sorted({k for d in knobs for k in d})
+    saved = {k: os.environ.get(k) for k in names}
+    first = {}
+    try:
+        for d in knobs:
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(d)
+            ctx = tor.Context(0)
+            ctx.upload(scene.list())
+            for accel in (0, 3):
+                got = _device_render(tor, ctx, cam, h, w, spp, seeding=tor.SEED_PIXEL, accel=accel,
+                                     pixel_kernel=tor.PIXEL_KERNEL_LANE).cpu().numpy()
+                if accel not in first:
+                    first[accel] = got
+                    _exact(got[rows], want)
+                assert np.array_equal(got, first[accel]), (d, accel)
+            # a row shard through the same schedule
+            part = _device_render(tor, ctx, cam, h, w, spp, seeding=tor.SEED_PIXEL, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE,
+                                  shard_index=1, shard_count=3, row_tile=2).cpu().numpy()
+            assert np.array_equal(part, first[0][tor.shard_rows(h, 2, 1, 3)]), d
+            if d == {}:
+                cost = ctx.last_pixel_cost(h * w)   # the probe of the last launch: the shard's pixels
+                assert len(cost) == len(tor.shard_rows(h, 2, 1, 3)) * w and cost.min() >= 2 and cost.max() <= 2 * 50
+            del ctx
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert np.array_equal(first[0], first[3])
