@@ -437,16 +437,17 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   tor::KParams p{};
   // Small SEED_PIXEL frames: one wave per pixel (coop_pixel_kernel) -- the lane-per-pixel kernel would be bound by
   // the latency of the longest pixel chain.  Same canvas bit for bit; needs only the float64 flat layout.
-  // Split fraction (measured: tools/split_sweep.py): the wave-per-pixel kernel saturates at ~285 Msamples/s, the
-  // lane kernel (with both exact accelerations) is bound by its longest chains; up to ~110 k pixels the two finish
-  // together with 45 % of the probed cost in the wave kernel, beyond that the best share shrinks like 20 000 / pixels
-  // (0.04 at 518 k, 0.02 at 922 k pixels: only the glass-sphere tiles), and from ~1.2 M pixels on the lane kernel is
-  // throughput bound and keeps everything.
+  // Split fraction (measured: tools/split_sweep.py, with the tiles ordered by their longest chain): the wave-per-pixel
+  // kernel saturates at ~285 Msamples/s, the lane kernel (with both exact accelerations) is bound by its longest chains;
+  // the best share of the probed work for the wave kernel is ~20 000 / pixels, capped at 0.2 (C1 at 100 spp: 16-17 ms for
+  // anything in 0.15-0.35, at 1000 spp 130 ms at 0.15 against 163 ms at 0.45) and floored at 0.02 (only the glass-sphere
+  // tiles); from ~1.2 M pixels on the lane kernel keeps everything.
   float split_frac = ctx->split_frac;
   if (split_frac < 0.0f) {
     split_frac = 0.0f;
     if (o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) && npix <= 1200000) {
-      split_frac = (npix <= 114688) ? 0.45f : 20000.0f / (float)npix;
+      split_frac = 20000.0f / (float)npix;
+      if (split_frac > 0.2f) split_frac = 0.2f;
       if (split_frac < 0.02f) split_frac = 0.02f;
     }
   }
