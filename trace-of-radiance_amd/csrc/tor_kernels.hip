@@ -268,6 +268,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const unsigned hot_iters = (SEEDING == 0 && p.sched != nullptr) ? (unsigned)p.sched[2] : 0u;
   bool a_done = from_back;
   unsigned pix_iters = 0;  // bounce iterations the lane has spent on its current pixel
+  // arbiter priorities (below): SEED_PIXEL without the cooperative resolve -- those variants are at their register
+  // limit (the lane counter costs them six more scratch stores per iteration) and their wave slots differ by 1.8x,
+  // not 4.6x: measured 1-2 % slower with the priorities than without
+  constexpr bool kPrio = SEEDING == 0 && !coop_variant(F32, BLOCKS);
   bool exhausted = false;
   // statistics (tor_last_stats / wave log) live in LDS and are touched only when they were asked for: the
   // kernel is short of scalar registers, counters that are always live would be paid for on every launch
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           have_item = true;
           if (SEEDING == 0) {
             seed2(rng, (uint64_t)(int64_t)row, (uint64_t)(int64_t)col);  // render.nim:59-60
-            pix_iters = 0;
+            if (kPrio) pix_iters = 0;
           }
         }
         w_next += take;
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       if (exhausted) break;
       continue;
     }
-    if (SEEDING == 0 && p.sched != nullptr) {
+    if (kPrio && p.sched != nullptr) {
       // Arbiter priority of the wave (s_setprio; the levels beat the age order):
       //  3  while one of its lanes works on a HOT pixel -- a chain so long (glass: up to ~36 queries per sample against
       //     a mean of 2.6) that even an average slot would finish it after everybody else.  Judged on the lane's own
