@@ -679,8 +679,11 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     // schedule of the lane kernel (tor_kernels.hip): two regions where some wave slot is slow enough to need it, and the
     // hot chains: a pixel chain is hot when it needs more than hot_frac of the iterations an average wave runs in this frame
     //   average = total probed queries * spp / probe_spp / lanes
-    const bool two_regions = ctx->back_slot > 0 && ctx->back_slot < waves_per_simd && ctx->tail_frac > 0.0f && (o.accel == 0 || ctx->back_accel);
-    p.back_slot = two_regions ? ctx->back_slot : 1 << 20;
+    // (TOR_BACK_SLOT=-1, a test setting: EVERY wave is treated as a slow-slot wave -- what a launch sees when other
+    // kernels hold the fast slots of the device)
+    const bool two_regions = (ctx->back_slot == -1 || (ctx->back_slot > 0 && ctx->back_slot < waves_per_simd)) && ctx->tail_frac > 0.0f &&
+                             (o.accel == 0 || ctx->back_accel);
+    p.back_slot = two_regions ? (ctx->back_slot == -1 ? 0 : ctx->back_slot) : 1 << 20;
     p.prio_shift = ctx->prio_shift;
     p.sched = slot_counters + 8;
     HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned)npix, tile_key, tile_key + n_tiles, (unsigned*)tile_order.ptr,

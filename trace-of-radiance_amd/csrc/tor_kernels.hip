@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const unsigned prio_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_ID.wave_id: the wave's slot in its SIMD
   unsigned prio_now = 0;
   // SEED_PIXEL tile schedule (see the fetch below): waves of the slow slots skip region A
-  const bool from_back = SEEDING == 0 && p.sched != nullptr && prio_slot >= (unsigned)p.back_slot;
+  bool from_back = SEEDING == 0 && p.sched != nullptr && prio_slot >= (unsigned)p.back_slot;
   const unsigned long long a_end = (SEEDING == 0 && p.sched != nullptr) ? p.sched[0] : p.total_work;
   // a pixel chain is HOT when, extrapolated from its samples so far, it needs more than hot_iters bounce iterations
   const unsigned hot_iters = (SEEDING == 0 && p.sched != nullptr) ? (unsigned)p.sched[2] : 0u;
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         unsigned grab = (SEEDING == 0) ? p.chunk : next_chunk;
         if (SEEDING != 0 && grab >= (unsigned)p.spp) grab = grab / (unsigned)p.spp * (unsigned)p.spp;
         unsigned long long base = 0;
+        bool retry = false;  // SEED_PIXEL: nothing fetched this time, but the wave is not done
         if (SEEDING == 0) {
           // Two regions of the chain-length-descending tile order (tile_order_kernel): A = [.., a_end) holds the long
           // chains, B = [a_end, total) the cheap end.  Waves in the fast hardware slots work through A and then B;
@@ -340,6 +341,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             if (take) {
               if (lane == leader) base = atomicAdd(p.sched + 1, (unsigned long long)kTilePixels);
               base = bcast_first_u64(__shfl(base, leader));
+              if (from_back && base >= p.total_work) {
+                // B ran dry while A still has tiles.  The hardware slot is only a hint about the wave's speed -- with
+                // other kernels on the device every wave of this launch may sit in a "slow" slot, and then nobody would
+                // render A: from here on the wave is a front wave (it asks A at its next fetch).
+                from_back = false;
+                a_done = false;
+                retry = true;
+              }
             }
           }
         } else {
@@ -347,8 +356,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           base = bcast_first_u64(__shfl(base, leader));
         }
         if (base >= p.total_work) {
-          exhausted = true;
-          if (prof && lane == 0) { prof_lds[kLogExhausted] = wall_clock64(); prof_lds[kLogItersAtExhaustion] = prof_lds[kStIters]; }
+          exhausted = !retry;
+          if (prof && lane == 0 && exhausted) { prof_lds[kLogExhausted] = wall_clock64(); prof_lds[kLogItersAtExhaustion] = prof_lds[kStIters]; }
         } else {
           w_next = base;
           w_end = (base + grab < p.total_work) ? base + grab : p.total_work;
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         if (p.prio_shift > 0) {
           const unsigned n_front = ((unsigned)p.back_slot < (unsigned)WAVES_PER_SIMD) ? (unsigned)p.back_slot : (unsigned)WAVES_PER_SIMD;
           const unsigned phase = (unsigned)(__builtin_readcyclecounter() >> p.prio_shift);
-          level = 1u + (prio_slot + phase) % (n_front < 2u ? n_front : 2u);
+          level = 1u + (prio_slot + phase) % (n_front < 2u ? 1u : 2u);
         }
       }
       if (level != prio_now) {
