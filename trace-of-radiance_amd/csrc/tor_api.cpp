@@ -311,9 +311,9 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->cam_ring.release();
   ctx->wave_log.release();
   for (int i = 0; i < TorContext::kRing; ++i) {
-    ctx->tile_cost[i].release();
     ctx->tile_order[i].release();
   }
+  ctx->probe_buf.release();
   ctx->scratch.release();
   ctx->slice.release();
   ctx->gather.release();
@@ -632,7 +632,9 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (o.seeding == TOR_SEED_PIXEL && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && n_tiles > 1) {
     // Cost-ordered schedule: a 2-spp probe (per-sample streams; it only counts closest-hit queries
     // per tile, it never touches the canvas) + a counting sort; ~2/spp of extra work.
-    DeviceBuffer& tile_cost = ctx->tile_cost[slot];
+    // (one buffer per context, not per ring slot: only the probe and the two sort kernels touch it, and the launches of a
+    // context are ordered on one stream)
+    DeviceBuffer& tile_cost = ctx->probe_buf;
     DeviceBuffer& tile_order = ctx->tile_order[slot];
     // per-pixel query counts of the probe, then per tile: sort key, probed work
     HIP_TRY(tile_cost.ensure(((size_t)npix + 2 * (size_t)n_tiles) * 4));
@@ -865,7 +867,7 @@ int64_t tor_last_pixel_cost(TorContext* ctx, uint32_t* out, int64_t cap_pixels) 
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipDeviceSynchronize());
   const int64_t n = ctx->last_probe_pixels < cap_pixels ? ctx->last_probe_pixels : cap_pixels;
-  HIP_TRY(hipMemcpy(out, ctx->tile_cost[ctx->last_slot].ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, ctx->probe_buf.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
   return n;
 }
 

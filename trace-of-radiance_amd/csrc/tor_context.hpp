@@ -111,7 +111,8 @@ struct TorContext {
   size_t bnd_slot_bytes = 0;
   // ---- per-launch state ----
   tor::DeviceBuffer counters;                      // kRing x 8 u64: [0] work counter, [1..4] stats, [5] probe counter
-  tor::DeviceBuffer tile_cost[kRing], tile_order[kRing];  // SEED_PIXEL cost-ordered schedule
+  tor::DeviceBuffer tile_order[kRing];  // SEED_PIXEL schedule: the tile order a launch reads
+  tor::DeviceBuffer probe_buf;          // ... and what the sort is made from: per-pixel probe counts, per-tile key and work
   int back_slot = 2;    // SEED_PIXEL: wave slots >= this take tiles from the cheap end (0 = none; TOR_BACK_SLOT)
   float hot_frac = 0.4f;   // a pixel chain is hot (arbiter priority 3) from this share of an average wave's iterations on (TOR_HOT_FRAC; 0 = off)
   float tail_frac = 0.2f;  // share of the lane kernel's probed work in region B of its schedule (TOR_TAIL_FRAC)
