@@ -903,6 +903,73 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           // bits or block-box bits, or ONE bit of a super-box entry (its 8 child boxes are slab-tested here) --
           // at most 8 list entries per lane and trip, so the lists (< 64 carried over + 512) cannot overflow.
           unsigned kq = 0, sup_mask = 0, sup_block = 0;
+          if constexpr (BLOCKS != 0) {
+            // Two-level scenes (more than 96 blocks): the slab loop left one bit per SUPER box (8 blocks) in box_mask, and
+            // the 8 child boxes of every super box a ray entered still have to be slab-tested for that ray.  Pooled like
+            // (B) and (C): every round packs up to 64 (ray, super box) units -- a prefix sum over the lanes' bit counts,
+            // the first lanes in scan order give as many as fit -- into the free space above the pending pairs, the 64
+            // lanes expand one unit each (the owner's box ray over ds_bpermute, the child boxes from LDS) and append
+            // the (ray, block) pairs: at most 512 on top of fewer than 64 carried over, the list holds 576.  Rounds =
+            // all the wave's units / 64 instead of the worst lane's count (measured on the 1601-object animation
+            // frames: 8+ per-lane trips of ~300 instructions before).
+            // (box_kind is set under `if (active)`: the test has to be made wave-uniform by hand, the block below is full
+            // of cross-lane operations)
+            const bool sup_lane = active && box_kind == 4;
+            if (ballot64(sup_lane) != 0) {
+              unsigned long long sm = sup_lane ? box_mask : 0ull;
+              if (sup_lane) box_mask = 0;
+              while (ballot64(sm != 0) != 0) {
+                const unsigned c = (unsigned)__builtin_popcountll(sm);
+                unsigned incl, total;
+                wave_scan_u32(c, incl, total);
+                const unsigned excl = incl - c;
+                unsigned take = excl >= 64u ? 0u : (c < 64u - excl ? c : 64u - excl);
+                const unsigned n_round = total < 64u ? total : 64u;
+                unsigned pos = n_pairs + excl;
+                for (; take != 0; --take) {
+                  const int b = __builtin_clzll(sm);  // super box b of the segment
+                  sm &= ~(0x8000000000000000ull >> b);
+                  coop_pair[pos++] = (unsigned)lane | ((box_group0 * kBlock + (unsigned)b) << 6);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                {
+                  const bool mine = (unsigned)lane < n_round;
+                  const unsigned e = mine ? coop_pair[n_pairs + (unsigned)lane] : (unsigned)lane;
+                  const int src = (int)(e & 63u);
+                  const unsigned rec = e >> 6;  // super box `rec`: its block boxes are rec*8 .. rec*8+7
+                  BoxRay32 ob;
+                  ob.ax = (f2v){__shfl(b32.ax.x, src), __shfl(b32.ax.y, src)};
+                  ob.ay = (f2v){__shfl(b32.ay.x, src), __shfl(b32.ay.y, src)};
+                  ob.az = (f2v){__shfl(b32.az.x, src), __shfl(b32.az.y, src)};
+                  ob.ix = splat2(__shfl(b32.ix.x, src)); ob.iy = splat2(__shfl(b32.iy.x, src)); ob.iz = splat2(__shfl(b32.iz.x, src));
+                  const unsigned owild = (unsigned)__shfl((int)r32.wild, src);
+                  unsigned mc = 0;
+                  if (mine) {
+                    auto child32 = [&](auto cb) {
+#pragma unroll 4
+                      for (int j = 0; j < kBlock; ++j)
+                        mc = (mc << 1) | slab_bit32(ob, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
+                                                    (f2v){cb[8 * j + 4], cb[8 * j + 5]});
+                    };
+                    if (p.bnd32_lds_floats > 0) child32(bnd32_lds + (size_t)rec * (8 * kBlock));
+                    else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
+                    mc |= owild;
+                  }
+                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane has read its unit: the space is free again
+                  if (prof && lane == 0) prof_lds[kSecTrips] += 1;
+                  unsigned at = reserve((unsigned)__builtin_popcount(mc), n_pairs);
+                  while (mc != 0) {
+                    const int bb = 31 - __builtin_clz(mc);
+                    mc &= ~(1u << bb);
+                    coop_pair[at++] = (unsigned)src | ((rec * kBlock + (unsigned)(7 - bb)) << 6);
+                  }
+                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                drain_b(false);
+                drain_c(false);
+              }
+            }
+          }
           {
             // Fast path (no super-box entries in the wave, everything fits the lists): count the bits of all
             // entries, ONE prefix sum for both lists (the two counts share a word), then write.
