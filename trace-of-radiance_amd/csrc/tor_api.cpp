@@ -537,7 +537,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
     p.shot_stride = hacc.hot_stride;
     // LDS staging of the compact records next to the per-wave queues (18 KB per workgroup, 160 KB per
-    // CU): it must fit at this mode's workgroups/CU, else one workgroup fewer, else global loads.
+    // CU): see the staging decision below.
     p.shot32 = nullptr;
     if (v32 && hacc.sp32) {
       p.shot32 = (const float*)ctx->d_accel[v32].hot32.ptr;
@@ -549,7 +549,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     // LDS staging of the block records next to the per-wave queues (10 KB per workgroup in these variants, 160 KB per CU): the
     // float32 pair records (TOR_ACCEL_F32; survivors are re-tested from the cold records -- staging the float64
     // records as well measured +2 % at best) or the float64 compact records.  It must fit at this mode's
-    // workgroups/CU, else one workgroup fewer, else global loads.
+    // workgroups/CU, else global loads (through L2).
     size_t hot_bytes = p.shot32 ? hacc.hot32.size() * 4 : hacc.hot.size() * 8;
     size_t bnd32_stage_floats = 0;
     if (p.shot32) {
@@ -565,12 +565,25 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     auto fits = [&](size_t bytes, int wgs) {
       return bytes <= hard_cap && bytes + (size_t)tor::integrate_fixed_lds_bytes(1, p.shot32 != nullptr ? 1 : 0) <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
     };
-    for (int tryw = ctx->max_blocks_per_cu[o.seeding][o.accel != 0]; tryw >= 2 && wg == 0; --tryw)
-      if (fits(hot_bytes, tryw)) wg = tryw;
-    p.shot_lds_doubles = (wg > 0 && !p.shot32) ? (int)hacc.hot.size() : 0;
-    p.shot32_lds_floats = (wg > 0 && p.shot32) ? (int)hacc.hot32.size() : 0;
-    // the block boxes ride along only if they do not cost a workgroup per CU
-    p.bnd32_lds_floats = (wg > 0 && p.shot32 && fits(hot_bytes + bnd32_stage_floats * 4, wg)) ? (int)bnd32_stage_floats : 0;
+    // Workgroups per CU come first: on the 1601-object animation frames 3 workgroups/CU reading the records through L2
+    // render 2339 Msamples/s, 2 workgroups/CU with the records in LDS 1914.  So the launch keeps its full workgroup count
+    // and stages what fits beside it: the block boxes of a two-level scene first (6.6 KB there; every lane reads 8 of
+    // them per super box it expands), then the block records if there is still room; only a launch whose mode runs at 2
+    // workgroups/CU anyway gets the bigger LDS share.
+    const int full = ctx->max_blocks_per_cu[o.seeding][o.accel != 0];
+    const bool stage_boxes = p.shot32 && bnd32_stage_floats > 0 && fits(bnd32_stage_floats * 4, full);
+    const size_t box_bytes = stage_boxes ? bnd32_stage_floats * 4 : 0;
+    bool stage_hot = fits(hot_bytes + box_bytes, full);
+    wg = (stage_hot || stage_boxes) ? full : 0;
+    if (!p.shot32 && !stage_hot && full > 2 && fits(hot_bytes, full - 1)) {
+      // (the float64 compact records of TOR_ACCEL_BLOCKS alone are read by every lane for every block it enters: there
+      // one workgroup fewer with the records in LDS wins, 1212 against 1140 Msamples/s on the same frames)
+      stage_hot = true;
+      wg = full - 1;
+    }
+    p.shot_lds_doubles = (stage_hot && !p.shot32) ? (int)hacc.hot.size() : 0;
+    p.shot32_lds_floats = (stage_hot && p.shot32) ? (int)hacc.hot32.size() : 0;
+    p.bnd32_lds_floats = stage_boxes ? (int)bnd32_stage_floats : 0;
   }
   // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
   // kernel variant's register budget follows it

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
   // TOR_ACCEL_BLOCKS: the block expansion gathers 8 x 64 B per lane and trip with 64 different
   // addresses; when the compact records fit they are staged in LDS once per workgroup.
-  const bool staged = BLOCKS && (p.shot_lds_doubles > 0 || p.shot32_lds_floats > 0);
+  const bool staged = BLOCKS && (p.shot_lds_doubles > 0 || p.shot32_lds_floats > 0 || p.bnd32_lds_floats > 0);
   double* stage = reinterpret_cast<double*>(smem_raw + (kThreads / 64) * kWaveLdsBytes);
   const ldptr shot_lds = (ldptr)stage;
   // (a launch stages either the float64 compact records or the float32 pair records)
