@@ -533,6 +533,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
     p.spatial_base = (int)hacc.spatial_base;
     p.n_super = (int)(((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) / tor::kPad);
+    p.two_level = hacc.two_level ? 1 : 0;
     p.shot = (const double*)ctx->d_accel[v32].hot.ptr;
     p.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
     p.shot_stride = hacc.hot_stride;

@@ -486,6 +486,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     // kCoop: TOR_ACCEL_BLOCKS | TOR_ACCEL_F32 resolve their candidates COOPERATIVELY (all 64 lanes, active or not,
     // work through the wave's (ray, block) pairs and (ray, object) survivors: see the resolve section below)
     constexpr bool kCoop = coop_variant(F32, BLOCKS);
+    // super boxes (two-level culling layouts, > 96 blocks): the cooperative variants carry that code only as BLOCKS = 2
+    // -- compiled into the single-level variants it cost them ~1 % (registers) -- the others always
+    constexpr bool kSuper = BLOCKS == 2 || (BLOCKS == 1 && F32 == 0);
     {
       // ================= (B) closest hit over all objects ==============================
       // hittables_lists.nim:48-55 with t_min = 0.001, t_max = Inf (render.nim:28)
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           // bits or block-box bits, or ONE bit of a super-box entry (its 8 child boxes are slab-tested here) --
           // at most 8 list entries per lane and trip, so the lists (< 64 carried over + 512) cannot overflow.
           unsigned kq = 0, sup_mask = 0, sup_block = 0;
-          if constexpr (BLOCKS != 0) {
+          if constexpr (kSuper) {
             // Two-level scenes (more than 96 blocks): the slab loop left one bit per SUPER box (8 blocks) in box_mask, and
             // the 8 child boxes of every super box a ray entered still have to be slab-tested for that ray.  Pooled like
             // (B) and (C): every round packs up to 64 (ray, super box) units -- a prefix sum over the lanes' bit counts,
@@ -974,14 +977,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             // Fast path (no super-box entries in the wave, everything fits the lists): count the bits of all
             // entries, ONE prefix sum for both lists (the two counts share a word), then write.
             if (!active) box_mask = 0;
-            bool has_super = box_kind == 4 && box_mask != 0;
+            bool has_super = kSuper && box_kind == 4 && box_mask != 0;
             unsigned cnt2 = has_super ? 0u : (unsigned)__builtin_popcountll(box_mask);  // pairs | direct survivors << 16
             for (unsigned k = 0; k < my_qn; ++k) {
               const unsigned e = q[k * 64];
               const unsigned k3 = e >> 30;
               const unsigned bits = (unsigned)__builtin_popcount(e & 0xffu);
               cnt2 += (k3 == 2) ? bits : ((k3 == 0) ? (bits << 16) : 0u);
-              has_super = has_super || (k3 == 1);
+              has_super = has_super || (kSuper && k3 == 1);
             }
             unsigned incl, total;
             wave_scan_u32(cnt2, incl, total);
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
           for (;;) {
             unsigned kind = 3, m = 0, blk = 0;  // 3: nothing this trip
-            if (BLOCKS != 0 && sup_mask != 0) {
+            if (kSuper && sup_mask != 0) {
               const int b = 31 - __builtin_clz(sup_mask);
               sup_mask &= ~(1u << b);
               const unsigned rec = sup_block * kBlock + (unsigned)(7 - b);  // super box `rec`: its block boxes are rec*8 .. rec*8+7
@@ -1038,13 +1041,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               const int g = __builtin_clzll(box_mask) >> 3;  // group of 8 boxes
               const unsigned mm = (unsigned)(box_mask >> (56 - 8 * g)) & 0xffu;
               box_mask &= ~(0xffull << (56 - 8 * g));
-              if (box_kind == 4) { sup_mask = mm; sup_block = box_group0 + (unsigned)g; kind = 4; }
+              if (kSuper && box_kind == 4) { sup_mask = mm; sup_block = box_group0 + (unsigned)g; kind = 4; }
               else { kind = 2; m = mm; blk = box_group0 + (unsigned)g; }
             } else if (kq < my_qn) {
               const unsigned e = q[kq * 64];
               kq += 1;
               const unsigned k3 = e >> 30;  // 0: object mask, 2: block boxes, 1: super boxes
-              if (k3 == 1) { sup_mask = e & 0xffu; sup_block = (e >> 8) & 0x3fffffu; kind = 4; }  // expanded bit by bit from the next trip on
+              if (kSuper && k3 == 1) { sup_mask = e & 0xffu; sup_block = (e >> 8) & 0x3fffffu; kind = 4; }  // expanded bit by bit from the next trip on
               else { kind = k3; m = e & 0xffu; blk = (e >> 8) & 0x3fffffu; }
             }
             if (ballot64(kind != 3) == 0) break;
@@ -1876,13 +1879,13 @@ __global__ void selftest_kernel(int op, const double* x, const double* y, double
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from tor_api.cpp)
 // ---------------------------------------------------------------------------------------
-// variant table: [seeding 0|1][arith 0|1][W 2|3][f32 0|1][blocks 0|1].  The block-expansion code (an unrolled
+// variant table: [seeding 0|1][arith 0|1][W 2|3][f32 0|1][blocks 0|1|2 (2: two-level layouts, cooperative variants only)].  The block-expansion code (an unrolled
 // 8-object stage per lane) is what makes the 168-register variants spill; launches without TOR_ACCEL_BLOCKS
 // use kernels compiled without it (no scratch traffic at all).
 typedef void (*IntegrateFn)(const KParams);
 static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32, int blocks) {
 #define TOR_V(S, A, W, F, B) if (seeding == S && arith == A && w == W && f32 == F && blocks == B) return integrate_kernel<S, A, W, F, B>;
-#define TOR_V4(S, A, W) TOR_V(S, A, W, 0, 0) TOR_V(S, A, W, 0, 1) TOR_V(S, A, W, 1, 0) TOR_V(S, A, W, 1, 1)
+#define TOR_V4(S, A, W) TOR_V(S, A, W, 0, 0) TOR_V(S, A, W, 0, 1) TOR_V(S, A, W, 1, 0) TOR_V(S, A, W, 1, 1) TOR_V(S, A, W, 1, 2)
   TOR_V4(0, 0, 2) TOR_V4(0, 1, 2) TOR_V4(1, 0, 2) TOR_V4(1, 1, 2)
   TOR_V4(0, 0, 3) TOR_V4(0, 1, 3) TOR_V4(1, 0, 3) TOR_V4(1, 1, 3)
   TOR_V4(2, 0, 3)   // cost probe of the SEED_PIXEL tile schedule
@@ -1897,7 +1900,7 @@ static int clamp_w(int waves_per_simd) {
 }
 
 static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
-static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? 1 : 0; }
+static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? ((p.two_level != 0 && wants_f32(p) != 0) ? 2 : 1) : 0; }
 static size_t dynamic_lds(const KParams& p) {
   return (size_t)wave_lds_bytes(wants_blocks(p), coop_variant(wants_f32(p), wants_blocks(p))) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
          (size_t)p.bnd32_lds_floats * 4;
