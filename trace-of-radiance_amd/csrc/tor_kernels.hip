@@ -128,7 +128,7 @@ constexpr int kCoopList = 576;
 // (+ the paths' attenuation: 3 x 64 float64 -- touched once per bounce, so it lives in LDS, not in 6 of the 168 registers)
 constexpr int coop_bytes(int blocks) { return (blocks ? 2 : 1) * kCoopList * 4 + 64 * 2 * 8 + 3 * 64 * 8; }  // (no pair list without boxes)
 constexpr int wave_lds_bytes(int blocks, int coop = 0) {
-  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) : 0);
+  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) + 64 : 0);
 }
 // Which kernel variants resolve cooperatively: TOR_ACCEL_BLOCKS | TOR_ACCEL_F32.  (The code also runs the variants
 // without boxes -- `blocks == 0 || f32 != 0` passes every parity test -- but there the candidates are few (1.25-1.43
@@ -184,15 +184,22 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  constexpr int kQCap = queue_cap(BLOCKS);
+  // SEED_PIXEL cooperative variants keep the pixel's running sum in LDS too (touched once per sample; as registers it is
+  // six of the 168, and the variant spills inside the bounce loop): it takes the upper half of the queue -- 4 entries are
+  // enough there, the box hits live in registers -- plus the SAMPLE accumulator cache this seeding does not use
+  constexpr bool kAccInLds = SEEDING == 0 && coop_variant(F32, BLOCKS);
+  constexpr int kQLayout = queue_cap(BLOCKS);          // queue entries the LDS layout reserves
+  constexpr int kQCap = kAccInLds ? 4 : kQLayout;      // ... and the ones this variant uses
+  constexpr int kAccPad = coop_variant(F32, BLOCKS) ? 64 : 0;
   constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS, coop_variant(F32, BLOCKS));
   unsigned char* wave_lds = smem_raw + wave * kWaveLdsBytes;
   unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
-  double* acc_lds = reinterpret_cast<double*>(wave_lds + kQCap * 64 * 4);          // [kAccSlots][3]
-  int* tag_lds = reinterpret_cast<int*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 24);  // [kAccSlots]
-  unsigned long long* prof_lds = reinterpret_cast<unsigned long long*>(wave_lds + kQCap * 64 * 4 + kAccSlots * 28);
+  double* acc_lds = reinterpret_cast<double*>(wave_lds + kQLayout * 64 * 4);          // [kAccSlots][3]
+  int* tag_lds = reinterpret_cast<int*>(wave_lds + kQLayout * 64 * 4 + kAccSlots * 24);  // [kAccSlots]
+  double* pix_acc = reinterpret_cast<double*>(wave_lds + 4 * 64 * 4) + lane;            // [3][64] (kAccInLds variants; ends kAccPad past the tags)
+  unsigned long long* prof_lds = reinterpret_cast<unsigned long long*>(wave_lds + kQLayout * 64 * 4 + kAccSlots * 28 + kAccPad);
   // cooperative resolve state (only carved out in the F32 && BLOCKS variants)
-  unsigned char* coop_base = wave_lds + kQCap * 64 * 4 + kAccSlots * 28 + kProfSlots * 8;
+  unsigned char* coop_base = wave_lds + kQLayout * 64 * 4 + kAccSlots * 28 + kAccPad + kProfSlots * 8;
   unsigned long long* coop_t = reinterpret_cast<unsigned long long*>(coop_base);   // [64] closest t so far (bit pattern)
   unsigned long long* coop_w = coop_t + 64;                                        // [64] (original index << 32) | cold slot at that t
   unsigned* coop_surv = reinterpret_cast<unsigned*>(coop_w + 64);                  // [kCoopList] lane | cold slot << 6
@@ -392,7 +399,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           if (SEEDING == 0) {
             pl = cur_pl + prefix;
             s = 0;
-            acc = v3(0, 0, 0);
+            if (kAccInLds) { pix_acc[0] = 0.0; pix_acc[64] = 0.0; pix_acc[128] = 0.0; }
+            else acc = v3(0, 0, 0);
           } else {  // sample and probe
             const unsigned t = cur_s + prefix;
             const unsigned dp = t / (unsigned)p.spp;
@@ -1315,12 +1323,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           path_q = 0;
         }
         if (SEEDING == 0) {
+          if (kAccInLds) acc = v3(pix_acc[0], pix_acc[64], pix_acc[128]);
           acc = acc + radiance;  // render.nim:67
           s += 1;
           if (s >= p.spp) {
             double* out = p.out + (size_t)pix * 3;
             out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
           } else {
+            if (kAccInLds) { pix_acc[0] = acc.x; pix_acc[64] = acc.y; pix_acc[128] = acc.z; }
             have_item = true;  // next sample of the same pixel, same stream
           }
         }
