@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           o = hp;
           d = nd;
           time = 0.0;
-          set_att(mul_att(get_att(), v3(1.0, 1.0, 1.0)));
+          // (materials.nim:63 attenuates by (1, 1, 1): x * 1.0 == x for every float64, so the product is not formed)
         }
         if (!ended) {
           depth += 1;
@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
           o = hp;
           d = nd;
           time = 0.0;
-          att = mul_att(att, v3(1.0, 1.0, 1.0));
+          // (attenuation (1, 1, 1), materials.nim:63: x * 1.0 == x, nothing to do)
         }
         if (absorbed) break;  // render.nim:38
       }
