@@ -1,4 +1,5 @@
-"""SEED_PIXEL lane kernel: two-ended tile queue (which hardware wave slots take from the cheap end) x workgroups per CU x priority rotation (each in a fresh context); canvases identical.
+"""SEED_PIXEL lane kernel schedule: workgroups per CU x slow wave slots (region B only) x priority period x
+region cut x hot-chain threshold, each in a fresh context; canvases must be identical.
 usage (GPU box): python tools/pixel_prio_sweep.py [spp] [accel]"""
 import hashlib, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           // chains, B = [a_end, total) the cheap end.  Waves in the fast hardware slots work through A and then B;
           // waves in the slow slots take from B only.  Why: the instruction arbiter serves the oldest wave of a SIMD
           // first -- 39 / 64 / 177 us per bounce iteration in wave slots 0 / 1 / 2 with three waves per SIMD -- and a
-          // pixel is one sequential chain of spp samples: the longest chains (glass, ~27 bounces per sample) need about
+          // pixel is one sequential chain of spp samples: the longest chains (glass, up to ~36 queries per sample) need about
           // as many iterations as an average wave runs in the whole frame, so they finish in time only in a fast slot;
           // in slot 2 they end the frame alone (measured: counter dry at 172 ms, last wave at 200-225 ms).  Equalising
           // the service with s_setprio makes it worse (64 us for everybody: every long chain is late).  Everybody ends
