@@ -12,7 +12,7 @@ H, W = (int(os.environ.get("H", 1080)), int(os.environ.get("W", 1920)))
 tor = importlib.import_module("trace-of-radiance_amd")
 scene, cam = tor.random_scene(0xFACADE), tor.camera()
 ref = None
-for waves, back, shift, stag, hot in [("3", "2", "16", "0.2", "0.4"), ("3", "2", "0", "0.2", "0.4"), ("3", "2", "16", "0.2", "0"), ("3", "2", "0", "0.2", "0"), ("3", "2", "16", "0.2", "0.8"), ("3", "2", "12", "0.2", "0.4")]:
+for waves, back, shift, stag, hot in [("3", "2", "16", "0.2", "0.4"), ("3", "2", "0", "0.2", "0"), ("3", "2", "16", "0.2", "0"), ("3", "2", "0", "0.2", "0.4"), ("3", "2", "14", "0.2", "0.4"), ("3", "2", "16", "0.2", "0.3"), ("3", "2", "16", "0.2", "0.6"), ("3", "2", "16", "0.3", "0.4")]:
     os.environ["TOR_TAIL_FRAC"] = stag
     os.environ["TOR_HOT_FRAC"] = hot
     os.environ["TOR_BACK_SLOT"] = back
@@ -24,7 +24,7 @@ for waves, back, shift, stag, hot in [("3", "2", "16", "0.2", "0.4"), ("3", "2",
     buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
     opt = tor.make_options(seeding=tor.SEED_PIXEL, accel=accel, pixel_kernel=tor.PIXEL_KERNEL_LANE)
     times = []
-    for rep in range(5):
+    for rep in range(9):
         ctx.render_device(cam, H, W, spp, 2.2, 50, opt, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         times.append(ctx.last_kernel_ms()[0])

@@ -476,6 +476,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           level = 1u + (prio_slot + phase) % (n_front < 2u ? 1u : 2u);
         }
       }
+      // (s_setprio is a scalar instruction: it must sit behind scalar branches.  Everything `level` depends on is the same
+      // in all lanes, but some of it is assigned under conditions the compiler cannot prove uniform; as a vector value the
+      // four s_setprio ended up in exec-masked regions and simply ran one after the other)
+      level = (unsigned)__builtin_amdgcn_readfirstlane((int)level);
       if (level != prio_now) {
         prio_now = level;
         if (level == 0) __builtin_amdgcn_s_setprio(0);
