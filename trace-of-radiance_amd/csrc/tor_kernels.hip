@@ -275,10 +275,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   const unsigned hot_iters = (SEEDING == 0 && p.sched != nullptr) ? (unsigned)p.sched[2] : 0u;
   bool a_done = from_back;
   unsigned pix_iters = 0;  // bounce iterations the lane has spent on its current pixel
-  // arbiter priorities (below): SEED_PIXEL without the cooperative resolve -- those variants are at their register
-  // limit (the lane counter costs them six more scratch stores per iteration) and their wave slots differ by 1.8x,
-  // not 4.6x: measured 1-2 % slower with the priorities than without
-  constexpr bool kPrio = SEEDING == 0 && !coop_variant(F32, BLOCKS);
+  // arbiter priorities (below): every SEED_PIXEL variant.  (In the cooperative variants the lane's iteration counter was
+  // one register too many while the pixel sum still lived in registers: 1-2 % slower then, 1-2 % faster at 100 spp now.)
+  constexpr bool kPrio = SEEDING == 0;
   bool exhausted = false;
   // statistics (tor_last_stats / wave log) live in LDS and are touched only when they were asked for: the
   // kernel is short of scalar registers, counters that are always live would be paid for on every launch
