@@ -127,7 +127,8 @@ enum {
 
 /* How the row shards of a multi-device tor_render_opt() reach the caller's canvas. */
 enum {
-  TOR_GATHER_AUTO = 0,  /* RCCL when the devices are distinct and librccl loads, else peer copies        */
+  TOR_GATHER_AUTO = 0,  /* RCCL when the devices are distinct, librccl loads and the communicator passes its
+                           self-check; if that leg fails: peer copies; if those fail: HOST (tor_last_note)   */
   TOR_GATHER_RCCL = 1,  /* single-process RCCL (ncclCommInitAll): every device sends its shard to
                            devices[0] over xGMI, one de-interleave kernel, one D2H (BASELINE north_star) */
   TOR_GATHER_PEER = 2,  /* the same with hipMemcpyPeerAsync instead of RCCL                              */
@@ -214,6 +215,11 @@ TOR_API int tor_last_render_timing(double out[5]);
 
 /* Thread-local description of the last failure (never NULL). */
 TOR_API const char* tor_last_error(void);
+
+/* Thread-local note of the last successful multi-device tor_render / tor_render_opt on this thread (never NULL): which
+ * gather ran ("gather: rccl" | "gather: peer" | "gather: host"), preceded by the legs TOR_GATHER_AUTO tried first and
+ * why they failed -- AUTO walks RCCL -> peer copies -> per-device D2H and never returns a wrong canvas.  Not an error. */
+TOR_API const char* tor_last_note(void);
 
 /* ------------------------------------------------------------------------------------ */
 /* Resident-context API (frame loops: trace_of_radiance_animation.nim:173-196; benchmarks; */
@@ -326,6 +332,13 @@ TOR_API int tor_last_stats(TorContext* ctx, TorStats* out);
  * refill + camera ray, object loop, exact resolve | shade, deposit, total}.
  * Returns the number of waves copied (<= cap_waves) or < 0. */
 TOR_API int tor_last_wave_log(TorContext* ctx, uint64_t* out, int64_t cap_waves);
+/* Debug: chain hand-off of the last TOR_SEED_PIXEL launch on this context (all 0 when the launch ran without it):
+ * out[0] tickets taken by server waves, out[1] chains pushed by lanes, out[2] waves still in the lane loop (0 after the
+ * launch), out[3] workgroups that were servers from the start, out[4] push threshold (bounce iterations), out[5] chains
+ * served, out[6] pushes of hot chains, out[7] pushes in the tail of the frame; out[8..11] microseconds after the
+ * kernel's start at which the work counter ran dry, the last wave left the lane loop, the last hot chain and the last
+ * tail chain were finished by a server; out[12], out[13] bounce iterations served for hot / tail chains. */
+TOR_API int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]);
 /* Debug: the cost probe of the last TOR_SEED_PIXEL launch (it runs from 32 spp on): closest-hit queries per pixel over the
  * probe's samples (2 per pixel; per-sample streams, so only statistically what the frame's samples do), in the shard's
  * local pixel order.  Returns the number of pixels copied (<= cap_pixels) or < 0 (no probe ran). */

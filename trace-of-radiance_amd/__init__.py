@@ -131,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_slab32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
-    "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost",
+    "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
 ]
 
 _lib = None
@@ -188,6 +188,7 @@ def lib():
     dp = C.POINTER(C.c_double)
     L.tor_last_error.restype = C.c_char_p
     L.tor_version.restype = C.c_char_p
+    L.tor_last_note.restype = C.c_char_p
     L.tor_render.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), HittableList, C.c_int64]
     L.tor_render_ptr.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), C.POINTER(HittableList), C.c_int64]
     L.tor_render_opt.argtypes = [C.POINTER(CanvasStruct), C.POINTER(Camera), HittableList, C.c_int64,
@@ -207,6 +208,7 @@ def lib():
     L.tor_last_wave_log.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
     L.tor_last_pixel_cost.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64]
     L.tor_last_pixel_cost.restype = C.c_int64
+    L.tor_last_handoff_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tor_camera_init.argtypes = [C.POINTER(Camera), C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Vec3)] + \
                                  [C.c_double] * 6
     L.tor_random_scene.argtypes = [C.c_uint64, C.POINTER(HittableVariant), C.c_int64]
@@ -439,6 +441,11 @@ def last_render_timing() -> dict:
     return {"upload_ms": t[0], "render_ms": t[1], "download_ms": t[2], "total_ms": t[3], "scene_cache_hit": bool(t[4])}
 
 
+def last_note() -> str:
+    """What the last multi-device render() on this thread chose / fell back to (tor_last_note)."""
+    return lib().tor_last_note().decode("utf-8", "replace")
+
+
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * 128)()
     _check(lib().tor_comm_unique_id(buf))
@@ -581,6 +588,14 @@ class Context:
         if n < 0:
             _check(int(n))
         return buf[:n]
+
+    def last_handoff_counters(self) -> dict:
+        """Chain hand-off of the last SEED_PIXEL launch (tor_last_handoff_counters)."""
+        out = (C.c_uint64 * 16)()
+        _check(lib().tor_last_handoff_counters(self._h, out))
+        names = ("tickets", "pushed", "lane_waves_left", "server_workgroups", "push_threshold", "served", "hot_pushes", "tail_pushes",
+                 "us_counter_dry", "us_lane_end", "us_hot_done", "us_tail_done", "its_hot", "its_tail")
+        return {k: int(v) for k, v in zip(names, out)}
 
     def last_wave_log(self, cap_waves: int = 16384) -> np.ndarray:
         buf = np.zeros((cap_waves, 8), dtype=np.uint64)

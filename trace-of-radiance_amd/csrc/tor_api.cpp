@@ -281,6 +281,17 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = std::getenv("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
   if (const char* c = std::getenv("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
+  if (const char* c = std::getenv("TOR_MIGRATE")) ctx->mig_mode = std::atoi(c);
+  if (const char* c = std::getenv("TOR_SRV_K")) ctx->srv_k = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_SRV_MIN_FRAC")) ctx->srv_min_frac = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_SRV_MAX_FRAC")) ctx->srv_max_frac = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_PUSH_THETA")) ctx->push_theta = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_FLOOR_THETA")) ctx->floor_theta = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_CHAIN_THETA")) ctx->chain_theta = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
+  if (const char* c = std::getenv("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
+  if (const char* c = std::getenv("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
+  if (const char* c = std::getenv("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
   if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
     for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
   e = ctx->counters.ensure(TorContext::kRing * TorContext::kSlotWords * sizeof(unsigned long long));
@@ -314,6 +325,8 @@ int tor_context_destroy(TorContext* ctx) {
     ctx->tile_order[i].release();
   }
   ctx->probe_buf.release();
+  ctx->mig_rec.release();
+  ctx->mig_flag.release();
   ctx->scratch.release();
   ctx->slice.release();
   ctx->gather.release();
@@ -451,10 +464,21 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       if (split_frac < 0.02f) split_frac = 0.02f;
     }
   }
-  const bool split_applies = o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
+  // Chain hand-off: the lane kernel pushes its long chains to server waves inside the same launch -- it
+  // replaces both the whole-frame wave kernel and split mode wherever the launch's kernel variant carries the servers
+  // (both exact accelerations, single-level culling layout with float32 records, <= 128 block boxes) and the probe runs.
+  bool mig_candidate = false;
+  if (o.seeding == TOR_SEED_PIXEL && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->mig_mode != 0 && o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) &&
+      ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && npix > tor::kTilePixelsHost && !ctx->collect_stats && ctx->n_objects > 0) {
+    const int rc = tor::ensure_layouts(ctx, o.accel);
+    if (rc != TOR_OK) return rc;
+    const tor::HostAccel& ha = ctx->accel[1];
+    mig_candidate = ctx->accel_built[1] && ha.available && ha.sp32 && !ha.two_level && (ha.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad <= 128;
+  }
+  const bool split_applies = !mig_candidate && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
                              npix >= ctx->split_min_pixels && npix <= ctx->split_max_pixels && !ctx->collect_stats && ctx->n_objects > 0;
   const bool want_wave_kernel = o.pixel_kernel == TOR_PIXEL_KERNEL_WAVE ||
-                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels && !split_applies);
+                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels && !split_applies && !mig_candidate);
   if (o.seeding == TOR_SEED_PIXEL && !ctx->collect_stats && want_wave_kernel && ctx->n_objects > 0) {
     const int rc = tor::ensure_layouts(ctx, 0);
     if (rc != TOR_OK) return rc;
@@ -625,6 +649,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (waves > resident_waves) waves = resident_waves;
   int blocks = (int)((waves + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
   if (blocks < 1) blocks = 1;
+  p.n_boxes = use_accel ? (int)((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) : 0;
+  p.mig = nullptr;
+  const bool migrate = mig_candidate && use_accel && n_tiles > 1 && tor::integrate_variant_serves_chains(p, o.seeding) && resident_waves >= 8;
+  if (migrate) blocks = (int)(resident_waves / (tor::kThreads / 64));  // the whole machine: waves without a tile are servers at once
   p.n_waves = (unsigned)(blocks * (tor::kThreads / 64));
   p.wave_log = nullptr;
   if (ctx->collect_stats) {
@@ -702,11 +730,40 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     p.back_slot = two_regions ? (ctx->back_slot == -1 ? 0 : ctx->back_slot) : 1 << 20;
     p.prio_shift = ctx->prio_shift;
     p.sched = slot_counters + 8;
+    tor::MigSchedule ms;
+    ms.key_mode = ctx->key_mode;
+    ms.probe_spp = ctx->probe_spp;
+    if (migrate) {
+      // queue of handed-over chains: 64-byte records + ready flags (zeroed per launch), control words in the ring slot
+      const size_t cap = (size_t)(npix < (1ll << 20) ? npix : (1ll << 20));
+      HIP_TRY(ctx->mig_rec.ensure(cap * 64));
+      HIP_TRY(ctx->mig_flag.ensure(cap * 4));
+      HIP_TRY(hipMemsetAsync(ctx->mig_flag.ptr, 0, cap * 4, stream));
+      p.mig = slot_counters + TorContext::kMigWord0;
+      p.mig_rec = (unsigned long long*)ctx->mig_rec.ptr;
+      p.mig_flag = (unsigned*)ctx->mig_flag.ptr;
+      p.mig_cap = (unsigned)cap;
+      p.mig_tail_lanes = ctx->mig_tail_lanes;
+      p.mig_flags = ctx->mig_flags;
+      p.mig_tail_rest = ctx->mig_tail_rest;
+      ms.mig = p.mig;
+      ms.lavg_scale = (float)spp / (float)ctx->probe_spp / ((float)blocks * (float)tor::kThreads);
+      ms.srv_k = ctx->srv_k;
+      ms.srv_min_frac = ctx->srv_min_frac;
+      ms.srv_max_frac = ctx->srv_max_frac;
+      ms.push_theta = ctx->push_theta;
+      ms.chain_scale = (float)spp / (float)ctx->probe_spp / (float)npix;
+      ms.chain_theta = ctx->chain_theta;
+      ms.floor_theta = ctx->floor_theta;
+      ms.blocks = blocks;
+      ms.spp = spp;
+      ms.max_depth = (int)max_depth;
+    }
     HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned)npix, tile_key, tile_key + n_tiles, (unsigned*)tile_order.ptr,
                                    (int)n_tiles, split ? split_frac : 0.0f, split ? slot_counters + 6 : nullptr,
                                    split ? slot_counters : nullptr, two_regions ? ctx->tail_frac : 0.0f,
                                    ctx->hot_frac > 0.0f ? ctx->hot_frac * (float)spp / (float)ctx->probe_spp / (float)(resident_waves * 64) : -1.0f,
-                                   p.sched, stream));
+                                   p.sched, ms, stream));
     p.order = (const unsigned*)tile_order.ptr;
     if (split) {
       if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -883,6 +940,24 @@ int64_t tor_last_pixel_cost(TorContext* ctx, uint32_t* out, int64_t cap_pixels) 
   const int64_t n = ctx->last_probe_pixels < cap_pixels ? ctx->last_probe_pixels : cap_pixels;
   HIP_TRY(hipMemcpy(out, ctx->probe_buf.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
   return n;
+}
+
+int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]) {
+  if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_handoff_counters: NULL argument");
+  if (ctx->launches < 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_handoff_counters: no launch yet");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long h[tor::kMigWords];
+  HIP_TRY(hipMemcpy(h, (unsigned long long*)ctx->counters.ptr + (size_t)ctx->last_slot * TorContext::kSlotWords + TorContext::kMigWord0, sizeof h,
+                    hipMemcpyDeviceToHost));
+  const int idx[8] = {tor::kMigHead, tor::kMigTail, tor::kMigLaneWaves, tor::kMigSrvWgs, tor::kMigPush, tor::kMigServed, tor::kMigHotPushes, tor::kMigTailPushes};
+  for (int k = 0; k < 8; ++k) out[k] = h[idx[k]];
+  // [8..12]: microseconds after the kernel's start: work counter dry, last wave out of the lane loop, last hot chain served, last tail chain served; 0 = never
+  const unsigned long long t0 = h[tor::kMigT0];
+  auto us = [&](unsigned long long t) { return (t == 0 || t == ~0ull || t < t0) ? 0ull : (t - t0) / 100ull; };
+  out[8] = us(h[tor::kMigTCounterDry]); out[9] = us(h[tor::kMigTLaneEnd]); out[10] = us(h[tor::kMigTHotDone]); out[11] = us(h[tor::kMigTTailDone]);
+  out[12] = h[tor::kMigItsHot]; out[13] = h[tor::kMigItsTail]; out[14] = 0; out[15] = 0;
+  return TOR_OK;
 }
 
 int tor_last_stats(TorContext* ctx, TorStats* out) {

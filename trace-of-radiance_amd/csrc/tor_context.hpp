@@ -18,6 +18,8 @@ namespace tor {
 
 int fail(int code, const std::string& msg);           // sets tor_last_error(), returns code
 int fail_hip(hipError_t e, const char* what);         // maps a HIP error to a TOR_ERR_* status
+void set_last_note(const std::string& s);             // tor_last_note(): what the last call chose / fell back to (not an error)
+const std::string& last_note();
 
 #define HIP_TRY(expr)                                        \
   do {                                                       \
@@ -90,7 +92,10 @@ struct RcclComm;  // tor_multi.cpp
 
 struct TorContext {
   static constexpr int kRing = 64;
-  static constexpr int kSlotWords = 16;  // 64-bit words per ring slot: work counter, 4 statistics, probe counter, split, wave-kernel counter, schedule (2)  // per-launch slots: events, camera, bounds, counters, tile schedule
+  // 64-bit words per ring slot: [0] work counter, [1..4] statistics, [5] probe counter, [6] split, [7] wave-kernel counter,
+  // [8..10] tile schedule, then from kMigWord0 on the chain hand-off's control lines (tor_kernels.hpp kMig*)
+  static constexpr int kMigWord0 = 16;
+  static constexpr int kSlotWords = kMigWord0 + tor::kMigWords;
   int device = 0;
   int num_cus = 0;
   // ---- scene: a byte copy of the caller's list (cache key + source of the lazily built layouts) ----
@@ -162,6 +167,18 @@ struct TorContext {
   long long split_min_pixels = 16384, split_max_pixels = 100000000;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork[kRing] = {}, ev_join[kRing] = {};
+  // Chain hand-off (SEED_PIXEL with both exact accelerations on a single-level layout, from lpt_min_spp on):
+  // lanes push long pixel chains to server waves inside the same launch.  TOR_MIGRATE=0 restores split mode / the
+  // wave-per-pixel kernel.  Knobs: TOR_SRV_K, TOR_SRV_MIN_FRAC, TOR_SRV_MAX_FRAC (dedicated server workgroups =
+  // clamp(srv_k / l_avg, min, max) of the launch), TOR_PUSH_THETA (hand over from theta x l_avg projected bounce
+  // iterations on), TOR_TAIL_LANES.
+  int mig_mode = 1;
+  float srv_k = 550.0f, srv_min_frac = 0.005f, srv_max_frac = 0.30f, push_theta = 3.0f, chain_theta = 3.5f, floor_theta = 1.33f;
+  int key_mode = 1;  // tile sort key of the SEED_PIXEL schedule (TOR_KEY_MODE; tor_kernels.hip tile_key_kernel)
+  int mig_tail_lanes = 8;
+  int mig_tail_rest = 1024;  // TOR_TAIL_REST
+  unsigned mig_flags = (8u << 8) | 2u;  // TOR_MIG_FLAGS (tor_kernels.hpp KParams::mig_flags)
+  tor::DeviceBuffer mig_rec, mig_flag;
 };
 
 namespace tor {

@@ -179,6 +179,13 @@ __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
   return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
 }
 
+// chain servers (defined after the kernel): whole waves that continue pixel chains handed over by the lanes
+template <int ARITH>
+__device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated);
+// which variants carry the hand-off: the reference's streams with both exact accelerations on a single-level layout --
+// what tor_render() runs by default
+constexpr bool migrate_variant(int seeding, int f32, int blocks) { return seeding == 0 && f32 != 0 && blocks == 1; }
+
 template <int SEEDING, int ARITH, int WAVES_PER_SIMD, int F32, int BLOCKS>
 __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -279,6 +286,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   // one register too many while the pixel sum still lived in registers: 1-2 % slower then, 1-2 % faster at 100 spp now.)
   constexpr bool kPrio = SEEDING == 0;
   bool exhausted = false;
+  // ---- chain hand-off -------------------------------------------------------------------------------
+  // A pixel is a sequential chain of spp samples (render.nim:59-67) and a lane needs ~16 us per bounce of it, so a frame
+  // cannot end before its longest chain x 16 us -- that, not the machine, bounds small frames, row shards of a multi-GPU
+  // job and the glass pixels of any frame.  Lanes therefore hand chains over at a sample boundary (state = pixel, samples
+  // done, RNG state, running sum: 64 bytes) to SERVER waves that give all 64 lanes to one chain (serve_chains below):
+  //   (a) hot: the chain's projected length (bounce iterations so far / samples so far x spp) exceeds the push threshold;
+  //   (b) tail: the wave has run out of fresh pixels and either few of its lanes are still alive or servers sit idle.
+  // Servers: the workgroups blockIdx.x < mig[kMigSrvWgs] from the start, and every wave that leaves the lane loop.
+  constexpr bool kMigrate = migrate_variant(SEEDING, F32, BLOCKS);
+  const bool mig_on = kMigrate && p.mig != nullptr;
+  if (mig_on && threadIdx.x == 0 && blockIdx.x == 0) p.mig[kMigT0] = wall_clock64();
+  const bool server_only = mig_on && (unsigned long long)blockIdx.x < ((const unsigned long long __attribute__((address_space(4)))*)(uintptr_t)p.mig)[kMigSrvWgs];
   // statistics (tor_last_stats / wave log) live in LDS and are touched only when they were asked for: the
   // kernel is short of scalar registers, counters that are always live would be paid for on every launch
   const bool stats_on = p.stats != nullptr;
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     prof_lds[kSecMark] = now_;                                    \
   }
 
-  for (;;) {
+  for (; !server_only;) {
     // ================= (A) refill lanes that have no live path =========================
     bool need_fetch = !active && !have_item;
     unsigned long long need_mask = ballot64(need_fetch);
@@ -363,6 +382,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         }
         if (base >= p.total_work) {
           exhausted = !retry;
+          if (kMigrate && p.mig != nullptr && exhausted && lane == 0) atomicMin(p.mig + kMigTCounterDry, (unsigned long long)wall_clock64());
           if (prof && lane == 0 && exhausted) { prof_lds[kLogExhausted] = wall_clock64(); prof_lds[kLogItersAtExhaustion] = prof_lds[kStIters]; }
         } else {
           w_next = base;
@@ -1339,6 +1359,62 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         }
       }
       }  // if (active)
+      if constexpr (kMigrate) {
+        // ---- hand the chain over at this sample boundary? ----
+        // (nothing of this is kept in registers across the bounce iteration -- the variant has none to spare: the control
+        // words are re-read through the scalar cache where they are needed)
+        unsigned long long* mq = p.mig;
+        asm volatile("" : "+s"(mq));
+        if (mq != nullptr) {
+          const bool boundary = ended && have_item;  // a sample just ended and the pixel has more
+          // the adaptive threshold (one relaxed load per wave and bounce; its line is written only by idle servers and pushers)
+          unsigned long long push_at = 0;
+          if (lane == 0) push_at = __hip_atomic_load(mq + kMigPushNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          push_at = bcast_first_u64(push_at);
+          const bool hot = boundary && s >= 8 && pix_iters >= 64u &&
+                           (unsigned long long)pix_iters * (unsigned)p.spp >= push_at * (unsigned)s;
+          bool tail_push = boundary && exhausted && !hot && p.mig_tail_lanes >= 0;
+          if (exhausted && p.mig_tail_lanes >= 0) {
+            const unsigned live = (unsigned)__builtin_popcountll(ballot64(active || have_item));
+            if (live > (unsigned)p.mig_tail_lanes) {
+              // more live lanes than the tail threshold: only as many chains as servers are waiting for one right now
+              unsigned long long hd = 0, tl = 0;
+              if (lane == 0) {
+                hd = __hip_atomic_load(mq + kMigHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tl = __hip_atomic_load(mq + kMigTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              hd = bcast_first_u64(hd);
+              tl = bcast_first_u64(tl);
+              const unsigned idle = hd > tl ? (unsigned)((hd - tl) > 64ull ? 64ull : (hd - tl)) : 0u;
+              // ... and only chains with a long way to go: a server bounce costs ~10 lane bounces, a short rest is cheaper here
+              const unsigned long long rest = (unsigned long long)(unsigned)(p.spp - s) * pix_iters / (unsigned)(s > 0 ? s : 1);
+              tail_push = tail_push && rest >= (unsigned long long)p.mig_tail_rest;
+              const unsigned long long tm = ballot64(tail_push);
+              tail_push = tail_push && lane_prefix(tm) < idle;
+            }
+          }
+          if (hot || tail_push) {
+            const unsigned long long at = atomicAdd(mq + kMigTail, 1ull);
+            if (at < (unsigned long long)p.mig_cap) {
+              unsigned long long* r = p.mig_rec + at * 8;
+              r[0] = (unsigned long long)(unsigned)pix | ((unsigned long long)(unsigned)s << 32) | (hot ? 1ull << 63 : 0ull);
+              r[1] = rng.s0; r[2] = rng.s1; r[3] = rng.s2; r[4] = rng.s3;
+              r[5] = double_to_bits(acc.x); r[6] = double_to_bits(acc.y); r[7] = double_to_bits(acc.z);
+              __hip_atomic_store(p.mig_flag + at, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+              have_item = false;  // the lane is free again
+              atomicAdd(mq + (hot ? kMigHotPushes : kMigTailPushes), 1ull);
+              if (hot && (p.mig_flags & 2u)) {
+                // adaptive threshold: a hot chain that finds others waiting in front of it raises the bar by 1/16
+                const unsigned long long hd = __hip_atomic_load(mq + kMigHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (at >= hd) {
+                  const unsigned long long now = __hip_atomic_load(mq + kMigPushNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(mq + kMigPushNow, now + (now >> 4) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+            }
+          }
+        }
+      }
     }
 
     TOR_SEC(kSecShade)
@@ -1377,6 +1453,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     TOR_SEC(kSecDeposit)
   }
 #undef TOR_SEC
+
+  if constexpr (kMigrate) {
+    if (mig_on) {
+      // every push of this wave happens-before the decrement: a server that reads 0 here has seen every record
+      if (!server_only && lane == 0) {
+        atomicMax(p.mig + kMigTLaneEnd, (unsigned long long)wall_clock64());
+        __hip_atomic_fetch_add(p.mig + kMigLaneWaves, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (kPrio && prio_now != 0) __builtin_amdgcn_s_setprio(0);
+      if (p.mig_tail_lanes > -2) serve_chains<ARITH>(p, server_only);  // (TOR_TAIL_LANES=-2: debugging, nobody serves -- only valid when nobody pushes)
+    }
+  }
 
   if (SEEDING == 1) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1688,6 +1776,276 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// serve_chains -- the SERVER side of the SEED_PIXEL chain hand-off, inside integrate_kernel<0, A, W, 1, 1>.
+//
+// A server is a whole wave that continues ONE pixel chain at a time from the state a lane pushed at a sample boundary
+// (pixel, samples done, xoshiro256+ state, running sum): the same stream, the same operations, the same pixel -- only the
+// closest-hit query is shared by the 64 lanes, as in coop_pixel_kernel, and here through the exact block culling as well:
+//   trip 1  lane L slab-tests block box L (and L + 64) in float32 (tor_filter32.hpp: slab_bit32, conservative);
+//   trip 2+ the candidates -- the always-tested objects, then the 8 objects of every box the ray can touch -- one per lane
+//           through the reference's float64 test (spheres.nim:28-49 / moving_spheres.nim:39-67, own operation order);
+//   then    a DPP min-reduction of t, ties to the lowest original index (hittables_lists.nim:48-55), and every lane runs
+//           the now wave-uniform scatter / RNG / sky code on identical values.
+// Any candidate set that contains the true closest hit gives the lane kernel's result bit for bit (closest hit is order
+// independent, every candidate gets the identical float64 test).  A bounce costs a server ~1-2 us instead of ~16 us in a
+// lane, at ~7x the instructions per bounce: worth it exactly for the chains that would otherwise end the frame alone.
+// Queue protocol: a server takes ticket i (atomic add on mig[kMigHead]) and waits for record i's ready flag; lanes take
+// slot i (atomic add on mig[kMigTail]), write the record, release the flag.  A server leaves when no wave is left in the
+// lane loop and its ticket lies beyond the last record.
+// ---------------------------------------------------------------------------------------------
+template <int ARITH>
+__device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated) {
+  const int lane = threadIdx.x & 63;
+  const double w_div = (double)(p.ncols - 1);  // render.nim:64
+  const double h_div = (double)(p.nrows - 1);
+  const cdptr cold = as_const(p.cold);
+  // this lane's block boxes: records lane and lane + 64 of the float32 boxes (constant for the launch)
+  const float nanf_ = __builtin_nanf("");
+  f2v bx0 = splat2(nanf_), by0 = bx0, bz0 = bx0, bx1 = bx0, by1 = bx0, bz1 = bx0;
+  const bool valid0 = lane < p.n_boxes, valid1 = lane + 64 < p.n_boxes;
+  {
+    const gfptr b = (gfptr)(uintptr_t)p.bnd32;
+    if (valid0) { const gfptr r = b + 8 * lane; bx0 = (f2v){r[0], r[1]}; by0 = (f2v){r[2], r[3]}; bz0 = (f2v){r[4], r[5]}; }
+    if (valid1) { const gfptr r = b + 8 * (lane + 64); bx1 = (f2v){r[0], r[1]}; by1 = (f2v){r[2], r[3]}; bz1 = (f2v){r[4], r[5]}; }
+  }
+  const unsigned n_always = (unsigned)p.spatial_base;
+  // the always-tested objects (cold slots [0, n_always)): lane L keeps record L's fields in registers
+  double ra0 = 0, ra1 = 0, ra2 = 0, ra3 = 0, ra4 = 0, ra5 = 0, ra7 = 0, ra8 = 1.0, ra13 = 0, ra14 = 0, ra15 = -1.0;
+  if ((unsigned)lane < n_always) {
+    const double* c = p.cold + (size_t)lane * 16;
+    ra0 = c[0]; ra1 = c[1]; ra2 = c[2]; ra3 = c[3]; ra4 = c[4]; ra5 = c[5]; ra7 = c[7]; ra8 = c[8]; ra13 = c[13]; ra14 = c[14]; ra15 = c[15];
+  }
+  const unsigned long long cap = (unsigned long long)p.mig_cap;
+  const unsigned max_waiting = (unsigned)p.mig_flags >> 16;  // 0: no limit
+  for (;;) {
+    if (max_waiting != 0 && !dedicated) {
+      // enough servers are waiting already: this wave leaves (a waiting wave is not free -- see the wait loop)
+      unsigned long long hd = 0, tl = 0;
+      if (lane == 0) {
+        hd = __hip_atomic_load(p.mig + kMigHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tl = __hip_atomic_load(p.mig + kMigTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      hd = bcast_first_u64(hd);
+      tl = bcast_first_u64(tl);
+      if (hd > tl && hd - tl >= (unsigned long long)max_waiting) break;
+    }
+    // ---- take a ticket, wait for its record (or for the end of the frame) ----
+    unsigned long long tk = atomicAdd(p.mig + kMigHead, lane == 0 ? 1ull : 0ull);  // (all lanes take part, see coop_pixel_kernel)
+    tk = bcast_first_u64(tk);
+    bool quit = false;
+    // Waiting: poll this ticket's own flag (one lane; the flags of consecutive tickets share a line, waiting servers are
+    // spread over many) with a growing back-off, and look at the end-of-frame words only every 8th poll -- thousands of
+    // waves wait here at the end of a frame and the lanes that still run must not queue behind their traffic.
+    unsigned polls = 0, naps = 1;
+    const unsigned max_naps = (unsigned)(p.mig_flags >> 8) & 0xffu;
+    for (;;) {
+      unsigned ready = 0;
+      if (lane == 0 && tk < cap) {
+        if (p.mig_flags & 1) ready = __hip_atomic_load(p.mig_flag + tk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        else ready = __hip_atomic_load(p.mig_flag + tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (__builtin_amdgcn_readfirstlane((int)ready) != 0) break;
+      if ((polls & 7u) == 7u || tk >= cap) {
+        unsigned long long running = 1;
+        if (lane == 0) running = __hip_atomic_load(p.mig + kMigLaneWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bcast_first_u64(running) == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          unsigned long long tail = 0;
+          if (lane == 0) tail = __hip_atomic_load(p.mig + kMigTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tail = bcast_first_u64(tail);
+          if (tail > cap) tail = cap;
+          if (tk >= tail) { quit = true; break; }
+        }
+      }
+      polls += 1;
+      if ((p.mig_flags & 2u) && lane == 0) {
+        // adaptive threshold: a server with nothing to do lowers the bar by 1/32 (never below the floor)
+        const unsigned long long now = __hip_atomic_load(p.mig + kMigPushNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long fl = __hip_atomic_load(p.mig + kMigPushFloor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long next = now - (now >> 5);
+        if (next < fl) next = fl;
+        if (next != now) __hip_atomic_store(p.mig + kMigPushNow, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (unsigned k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
+      if (naps < max_naps) naps *= 2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the record's words were written before the flag was released
+    if (quit) break;
+    unsigned long long rec[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rec[k] = bcast_first_u64(__hip_atomic_load(p.mig_rec + tk * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned pl = (unsigned)rec[0];
+    const int s_begin = (int)((rec[0] >> 32) & 0x7fffffffull);
+    const bool was_hot = (rec[0] >> 63) != 0;
+    unsigned chain_its = 0;
+    Rng rng{rec[1], rec[2], rec[3], rec[4]};
+    V3 acc = v3(bits_to_double(rec[5]), bits_to_double(rec[6]), bits_to_double(rec[7]));
+    const unsigned lrow = pl / (unsigned)p.ncols;
+    const int col = (int)(pl - lrow * (unsigned)p.ncols);
+    const unsigned rtile = lrow / (unsigned)p.row_tile;
+    const unsigned within = lrow - rtile * (unsigned)p.row_tile;
+    const int row = (int)((rtile * (unsigned)p.shard_count + (unsigned)p.shard_index) * (unsigned)p.row_tile + within);
+    __builtin_amdgcn_s_setprio(3);
+    for (int s = s_begin; s < p.spp; ++s) {
+      // render.nim:64-66
+      const double u = ((double)col + uniform01(rng)) / w_div;
+      const double v = ((double)row + uniform01(rng)) / h_div;
+      const Camera cam = load_camera(p.cam_dev);
+      const Ray r0 = camera_ray(cam, u, v, rng);
+      V3 o = r0.origin, d = r0.direction, att = v3(1.0, 1.0, 1.0);
+      double time = r0.time;
+      V3 radiance = v3(0.0, 0.0, 0.0);  // absorbed / loop exhausted -> black (render.nim:38,47)
+      for (int depth = 0; depth < p.max_depth; ++depth) {
+        // ---- closest hit (hittables_lists.nim:48-55), boxes and candidates split across the lanes ----
+        chain_its += 1;
+        const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+        const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
+        const double a = (ARITH == 0) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
+        const RayF32 r32 = make_ray_f32(ox, oy, oz, dx, dy, dz, a_strict, p.org[0], p.org[1], p.org[2]);
+        const BoxRay32 b32 = make_box_ray32(r32, p.sp_bmax);
+        const unsigned wild = r32.wild & 1u;  // a ray outside the float32 test's guarded ranges enters every box
+        const unsigned long long m0 = ballot64(valid0 && ((slab_bit32(b32, bx0, by0, bz0) | wild) != 0u));
+        const unsigned long long m1 = ballot64(valid1 && ((slab_bit32(b32, bx1, by1, bz1) | wild) != 0u));
+        const unsigned n_cand = n_always + 8u * (unsigned)(__builtin_popcountll(m0) + __builtin_popcountll(m1));
+        const double f_sp = (time - p.sp_t0) / p.sp_dt;  // moving_spheres.nim:42 for the spatial movers' (time0, time1)
+        double best_t = __builtin_inf();
+        int best_slot = -1, best_orig = 0x7fffffff;
+        for (unsigned base = 0; base < n_cand; base += 64u) {
+          const unsigned i = base + (unsigned)lane;
+          int slot = -1;
+          if (i < n_always) {
+            slot = (int)i;
+          } else if (i < n_cand) {
+            // the (i - n_always)/8-th box the ray touches: a wave-uniform walk over the set bits
+            const unsigned want = (i - n_always) >> 3;
+            unsigned rank = 0;
+            int box = 0;
+            for (unsigned long long m = m0; m != 0; m &= m - 1, ++rank)
+              if (rank == want) box = (int)__builtin_ctzll(m);
+            for (unsigned long long m = m1; m != 0; m &= m - 1, ++rank)
+              if (rank == want) box = 64 + (int)__builtin_ctzll(m);
+            slot = p.spatial_base + 8 * box + (int)((i - n_always) & 7u);
+          }
+          if (slot >= 0) {
+            // The record's fields in ONE batch of loads, used without a branch in between: a server's bounce is a chain of
+            // dependent steps, every extra round trip to L2 is paid in full.  (The always-tested objects -- the first
+            // n_always candidates of every query -- sit in registers: ra*.)
+            const double* c = p.cold + (size_t)slot * 16;
+            const bool in_regs = i < n_always && i < 64u;
+            double k0, k1, k2, k3, k4, k5, k7, k8, k13, k14, k15;
+            if (in_regs) {
+              k0 = ra0; k1 = ra1; k2 = ra2; k3 = ra3; k4 = ra4; k5 = ra5; k7 = ra7; k8 = ra8; k13 = ra13; k14 = ra14; k15 = ra15;
+            } else {
+              k0 = c[0]; k1 = c[1]; k2 = c[2]; k3 = c[3]; k4 = c[4]; k5 = c[5]; k7 = c[7]; k8 = c[8]; k13 = c[13]; k14 = c[14]; k15 = c[15];
+            }
+            const bool moving = ((int)__double_as_longlong(k13) & 1) != 0;
+            double f = f_sp;  // (the spatial movers share one time group: same operands as the division, same quotient)
+            if (moving && !(k7 == p.sp_t0 && k8 == p.sp_dt)) f = (time - k7) / k8;
+            double mx, my, mz;  // centre of a mover (moving_spheres.nim:43); a static sphere keeps c0 untouched
+            if (ARITH == 0) { mx = k0 + k3 * f; my = k1 + k4 * f; mz = k2 + k5 * f; }
+            else { mx = fma_(k3, f, k0); my = fma_(k4, f, k1); mz = fma_(k5, f, k2); }
+            const double cx = moving ? mx : k0, cy = moving ? my : k1, cz = moving ? mz : k2;
+            const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+            double hb, cc, disc;
+            if (ARITH == 0) {
+              hb = ocx * dx + ocy * dy + ocz * dz;             // spheres.nim:31
+              cc = (ocx * ocx + ocy * ocy + ocz * ocz) - k15;  // spheres.nim:32
+              disc = hb * hb - a * cc;                         // spheres.nim:33
+            } else {
+              hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+              cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -k15)));
+              disc = fma_(hb, hb, -(a * cc));
+            }
+            // both roots are <= 0 when half_b >= 0 and c >= 0: such an object can never be accepted (t_min = 0.001)
+            if (disc > 0.0 && (hb < 0.0 || cc < 0.0)) {
+              const double root = __builtin_sqrt(disc);  // spheres.nim:35-48
+              double sol = (-hb - root) / a;
+              bool ok = (0.001 < sol) && (sol < __builtin_inf());
+              if (!ok) {
+                sol = (-hb + root) / a;
+                ok = (0.001 < sol) && (sol < __builtin_inf());
+              }
+              if (ok) {
+                const int orig = (int)__double_as_longlong(k14);
+                if (sol < best_t || (sol == best_t && orig < best_orig)) { best_t = sol; best_slot = slot; best_orig = orig; }
+              }
+            }
+          }
+        }
+        const double t_min = wave_min_f64(best_t);
+        if (!(t_min < __builtin_inf())) {
+          radiance = sky(d, att);  // render.nim:41-45
+          break;
+        }
+        unsigned long long win = ballot64(best_t == t_min);
+        if (win & (win - 1)) {  // several lanes at the same t (duplicate objects): the lowest original index wins
+          const int o_min = wave_min_i32(best_t == t_min ? best_orig : 0x7fffffff);
+          win = ballot64(best_t == t_min && best_orig == o_min);
+        }
+        const int slot = __builtin_amdgcn_readlane(best_slot, (int)__builtin_ctzll(win));
+        // ---- shade: wave-uniform (every lane holds the same values) ----
+        const cdptr c = cold + (size_t)slot * 16;
+        const int flags = (int)__double_as_longlong(c[13]);
+        V3 center = v3(c[0], c[1], c[2]);
+        if (flags & 1) {
+          const double hit_f = (c[7] == p.sp_t0 && c[8] == p.sp_dt) ? f_sp : (time - c[7]) / c[8];
+          if (ARITH == 0) center = center + v3(c[3], c[4], c[5]) * hit_f;
+          else center = v3(fma_(c[3], hit_f, c[0]), fma_(c[4], hit_f, c[1]), fma_(c[5], hit_f, c[2]));
+        }
+        const V3 hp = o + d * t_min;               // rays.nim:24-25
+        const V3 outward = (hp - center) * c[6];   // spheres.nim:43
+        const bool front = dot(d, outward) < 0.0;  // core.nim:47-49
+        const V3 n = front ? outward : -outward;
+        const int mat = (flags >> 8) & 0xff;
+        const V3 albedo = v3(c[9], c[10], c[11]);
+        bool absorbed = false;
+        if (mat == kLambertian) {  // materials.nim:24-30
+          d = n + random_unit_vector(rng);
+          o = hp;
+          att = mul_att(att, albedo);
+        } else if (mat == kMetal) {  // materials.nim:39-47
+          const V3 reflected = reflect(unit_vector(d), n);
+          const V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
+          o = hp;
+          d = nd;
+          time = 0.0;
+          if (dot(nd, n) > 0.0) att = mul_att(att, albedo);
+          else absorbed = true;
+        } else {  // materials.nim:62-86
+          const double eta = front ? c[9] : c[12];  // 1.0 / ri : ri
+          const V3 ud = unit_vector(d);
+          const double dn = dot(-ud, n);
+          const double cos_theta = (dn <= 1.0) ? dn : 1.0;
+          const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+          V3 nd;
+          if (eta * sin_theta > 1.0) {
+            nd = reflect(ud, n);
+          } else {
+            const double reflect_prob = schlick_r0(cos_theta, front ? c[10] : c[11]);
+            if (uniform01(rng) < reflect_prob) nd = reflect(ud, n);
+            else nd = refract(ud, n, eta);
+          }
+          o = hp;
+          d = nd;
+          time = 0.0;
+          // (attenuation (1, 1, 1), materials.nim:63: x * 1.0 == x, nothing to do)
+        }
+        if (absorbed) break;  // render.nim:38
+      }
+      acc = acc + radiance;  // render.nim:67
+    }
+    __builtin_amdgcn_s_setprio(0);
+    double* out = p.out + (size_t)pl * 3;  // every lane holds the same sum
+    out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+    if (lane == 0) {
+      atomicAdd(p.mig + kMigServed, 1ull);
+      atomicAdd(p.mig + (was_hot ? kMigItsHot : kMigItsTail), (unsigned long long)chain_its);
+      atomicMax(p.mig + (was_hot ? kMigTHotDone : kMigTTailDone), (unsigned long long)wall_clock64());
+    }
+  }
+}
+
 // Tile schedule for SEED_PIXEL: counting sort of the tiles by probed cost, most expensive first
 // (longest-processing-time-first: a pixel is a sequential chain of spp samples, so the expensive
 // chains must start at t = 0).  One workgroup; the order of equal-cost tiles is irrelevant (the
@@ -1699,7 +2057,7 @@ constexpr int kCostBins = 4096;
 // glass sphere has a few 27-bounce pixels among sky: by its sum it would start mid-frame and its chains would end the
 // frame) -- with the tile's sum as the tie-breaker; the sum itself is kept for the work accounting of the cuts.
 __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cost, unsigned n_pixels, int n_tiles, unsigned* key,
-                                                        unsigned* work) {
+                                                        unsigned* work, unsigned key_mode, unsigned probe_spp) {
   const int tile = (int)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64);
   if (tile >= n_tiles) return;
   const unsigned pl = (unsigned)tile * kTilePixels + (threadIdx.x & 63);
@@ -1711,9 +2069,20 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cos
     sum += os;
   }
   if ((threadIdx.x & 63) == 0) {
-    const unsigned m = mx < 127u ? mx : 127u;        // 2 samples x max_depth 50 <= 100 (more only with a deeper max_depth)
-    const unsigned t = (sum >> 8) < 31u ? (sum >> 8) : 31u;
-    key[tile] = (m << 5) | t;
+    if (key_mode == 0) {  // round-2 key: the tile's longest probed pixel, the sum breaks ties
+      const unsigned m = mx < 127u ? mx : 127u;        // 2 samples x max_depth 50 <= 100 (more only with a deeper max_depth)
+      const unsigned t = (sum >> 8) < 31u ? (sum >> 8) : 31u;
+      key[tile] = (m << 5) | t;
+    } else {
+      // Two classes.  A pixel whose probe samples were ALL deep (>= 28 queries per sample on average: inside glass) is a
+      // long chain for certain -- one deep path among ordinary ones is not, half of all tiles hold one -- and its tile must
+      // start first: upper half of the key space, by that pixel's count.  Every other tile is ordered by its SUM: 64 pixels
+      // x the probe's samples predict the mean cost of the tile's chains well, and the frame should end on the cheapest
+      // chains (the tail of a frame is as long as the chains that are started last).
+      const unsigned per2 = 2u * mx / probe_spp, sum2 = 2u * sum / probe_spp;  // normalised to 2 probe samples
+      if (per2 >= 56u) key[tile] = 2048u + ((per2 < 127u ? per2 : 127u) << 4) + ((sum2 >> 6) < 15u ? (sum2 >> 6) : 15u);
+      else key[tile] = sum2 < 2047u ? sum2 : 2047u;
+    }
     work[tile] = sum > 0 ? sum : 1u;
   }
 }
@@ -1729,7 +2098,7 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cos
 __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, const unsigned* work, unsigned* order, int n_tiles,
                                                           float split_frac, unsigned long long* split_out,
                                                           unsigned long long* lane_counter, float tail_frac, float hot_chain,
-                                                          unsigned long long* sched) {
+                                                          unsigned long long* sched, const MigSchedule mig) {
   __shared__ unsigned hist[kCostBins];
   __shared__ unsigned offs[kCostBins];
   __shared__ unsigned long long bin_work[kCostBins];
@@ -1781,6 +2150,43 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, c
       sched[1] = (unsigned long long)k_tail * kTilePixels;
       // hot chains: hot_chain x the probed total, scaled by the host to bounce iterations of the frame
       sched[2] = hot_chain > 0.0f ? (unsigned long long)(hot_chain * (float)total) + 1ull : 0ull;
+    }
+    if (mig.mig != nullptr) {
+      // Chain hand-off (integrate_kernel / serve_chains).  l_avg = bounce iterations an average lane runs in this frame.
+      // The longest chains (glass: ~34 queries per sample whatever the frame) are a fixed number of iterations, so the
+      // smaller l_avg -- a small frame, a row shard of a multi-GPU job -- the larger their share of the frame time and
+      // the more servers must stand ready from the start: dedicated server workgroups = srv_k / l_avg of the launch,
+      // clamped.  A chain is handed over once its projected length exceeds push_theta x l_avg.
+      const float l_avg = (float)total * mig.lavg_scale;
+      // push threshold: push_theta x l_avg, but never below chain_theta x the frame's MEAN chain -- on a frame with fewer
+      // pixels than lanes l_avg says nothing about how long a chain is
+      const float mean_chain = (float)total * mig.chain_scale;
+      float push = mig.push_theta * l_avg;
+      if (push < mig.chain_theta * mean_chain) push = mig.chain_theta * mean_chain;
+      if (push < 64.0f) push = 64.0f;
+      float frac = l_avg > 0.0f ? mig.srv_k / l_avg : mig.srv_max_frac;
+      frac = frac < mig.srv_min_frac ? mig.srv_min_frac : (frac > mig.srv_max_frac ? mig.srv_max_frac : frac);
+      // no chain of this frame can reach the threshold (a sample has at most max_depth queries; the longest chains of a
+      // scene with glass run at ~0.7 of that): nobody will push early, keep the minimum
+      if ((float)mig.spp * 0.7f * (float)mig.max_depth < push) frac = mig.srv_min_frac;
+      int n_srv = (int)(frac * (float)mig.blocks + 0.999f);
+      // waves that never get a tile (frames with fewer tiles than waves) are servers from the start anyway
+      const int free_wgs = (mig.blocks * (kThreads / 64) - n_tiles) / (kThreads / 64);
+      if (free_wgs > 0) n_srv = n_srv > free_wgs ? n_srv - free_wgs : 0;
+      if (n_srv > mig.blocks - 1) n_srv = mig.blocks - 1;
+      if (n_srv < 0) n_srv = 0;
+      mig.mig[kMigTCounterDry] = ~0ull;
+      mig.mig[kMigSrvWgs] = (unsigned long long)n_srv;
+      mig.mig[kMigLaneWaves] = (unsigned long long)(mig.blocks - n_srv) * (kThreads / 64);
+      mig.mig[kMigPush] = (unsigned long long)push;
+      // the adaptive threshold starts there and moves between it ... and the length from which a chain cannot finish in a lane
+      // before the frame does (floor_theta x l_avg; same floor from the mean chain as above)
+      float fl = mig.floor_theta * l_avg;
+      if (fl < mig.chain_theta * mean_chain) fl = mig.chain_theta * mean_chain;
+      if (fl < 64.0f) fl = 64.0f;
+      if (fl > push) fl = push;
+      mig.mig[kMigPushFloor] = (unsigned long long)fl;
+      mig.mig[kMigPushNow] = (unsigned long long)push;
     }
   }
   __syncthreads();
@@ -1928,11 +2334,16 @@ hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
 
 hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
                              float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
-                             float hot_chain, unsigned long long* sched, hipStream_t stream) {
-  hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, pixel_cost, n_pixels, n_tiles, key, work);
+                             float hot_chain, unsigned long long* sched, const MigSchedule& mig, hipStream_t stream) {
+  hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, pixel_cost, n_pixels, n_tiles, key, work,
+                     (unsigned)mig.key_mode, (unsigned)(mig.probe_spp > 0 ? mig.probe_spp : 2));
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned*)key, (const unsigned*)work, order, n_tiles, split_frac,
-                     split_out, lane_counter, tail_frac, hot_chain, sched);
+                     split_out, lane_counter, tail_frac, hot_chain, sched, mig);
   return hipGetLastError();
+}
+
+bool integrate_variant_serves_chains(const KParams& p, int seeding) {
+  return migrate_variant(seeding, wants_f32(p), wants_blocks(p)) && p.bnd32 != nullptr && p.shot32 != nullptr;
 }
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,

@@ -78,6 +78,40 @@ struct KParams {
   int n_cold_slots, coop_slots;
   const unsigned long long* split;  // split mode: number of cost-ordered tiles the wave kernel takes (device word), else null
   const double* coop_trips;  // 4 float64 per trip of 64 slots {kind, time0, time1 - time0, 0} (tor_scene.hpp)
+  // SEED_PIXEL chain hand-off (tor_kernels.hip "chain servers"); null = off.  Lanes push the state of a pixel
+  // chain at a sample boundary -- {pixel, samples done, RNG state, running sum} -- and whole waves ("servers") continue it,
+  // the 64 lanes sharing each closest-hit query: same arithmetic, same pixel, a tenth of the latency per bounce.
+  unsigned long long* mig;      // control words, kMig* below (zero before the launch; tile_order_kernel fills the schedule part)
+  unsigned long long* mig_rec;  // mig_cap records of 8 x u64 {pixel | samples done << 32, rng s0..s3, sum x y z}
+  unsigned* mig_flag;           // mig_cap ready flags (zero before the launch)
+  unsigned mig_cap;
+  int mig_tail_lanes;           // a wave that has run out of fresh pixels hands its chains over from this many live lanes down
+  int mig_tail_rest;            // ... with more live lanes than that: only chains with at least this many bounce iterations to go, and only to idle servers
+  unsigned mig_flags;           // bit 0: acquire (not relaxed) polling; bit 1: adaptive push threshold; bits 8-15: longest back-off of a waiting server in naps of ~3.4 us; bits 16-31: at most this many waiting servers (0 = no limit)
+  int n_boxes;                  // block boxes of a single-level culling layout (padded to kPad), the servers' first trip
+};
+
+// Control words of the hand-off, one 128-byte line per access pattern (thousands of waiting servers poll their flags and,
+// rarely, kMigLaneWaves; the lanes must never queue behind that traffic):
+enum : int {
+  kMigHead = 0,        // line 0: tickets taken by servers (ticket i waits for record i)
+  kMigTail = 16,       // line 1: records pushed by lanes
+  kMigLaneWaves = 32,  // line 2: waves still inside the lane loop (set by tile_order_kernel; a server leaves when this is 0 and its ticket >= tail)
+  kMigSrvWgs = 48,     // line 3, constant during the launch (read through the scalar cache): workgroups (blockIdx < this) that are servers from the start
+  kMigPush = 49,       //         initial push threshold: a chain is handed over once its projected length exceeds this many bounce iterations
+  kMigPushFloor = 50,  //         ... and the value the adaptive threshold never goes below
+  kMigServed = 64,     // line 4, diagnostics: chains served, hot pushes, tail pushes
+  kMigHotPushes = 65,
+  kMigTailPushes = 66,
+  kMigT0 = 67,         // 100 MHz wall clock: first wave's start, last wave leaving the lane loop, last hot / tail chain finished
+  kMigTLaneEnd = 68,
+  kMigTHotDone = 69,
+  kMigTTailDone = 70,
+  kMigItsHot = 71,     // bounce iterations served for hot / tail chains
+  kMigItsTail = 72,
+  kMigTCounterDry = 73,  // first wave that found the work counter dry
+  kMigPushNow = 80,    // line 5: the ADAPTIVE push threshold (lanes read it every bounce; idle dedicated servers lower it, pushers that meet a backlog raise it)
+  kMigWords = 96
 };
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
@@ -88,9 +122,20 @@ int coop_blocks_per_cu(const KParams& p, int arith);  // 0: the objects do not f
 hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream);
 int integrate_fixed_lds_bytes(int blocks, int coop);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists)
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
+// schedule of the chain hand-off, computed on the device from the probe's total (tile_order_kernel): l_avg = probed queries x
+// lavg_scale = bounce iterations an average lane runs in this frame; dedicated server workgroups = clamp(srv_k / l_avg, ..) x
+// blocks; push threshold = push_theta x l_avg
+struct MigSchedule {
+  unsigned long long* mig = nullptr;
+  float lavg_scale = 0.f, srv_k = 0.f, srv_min_frac = 0.f, srv_max_frac = 0.f, push_theta = 0.f;
+  float chain_scale = 0.f, chain_theta = 0.f, floor_theta = 0.f;  // mean chain of the frame = probed queries x chain_scale; the threshold's floor = chain_theta x that
+  int blocks = 0, spp = 0, max_depth = 0;
+  int key_mode = 0, probe_spp = 2;  // tile sort key (tile_key_kernel): 0 = longest probed pixel, 1 = certain long chains first, then by the tile's sum
+};
 hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
                              float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
-                             float hot_chain, unsigned long long* sched, hipStream_t stream);
+                             float hot_chain, unsigned long long* sched, const MigSchedule& mig, hipStream_t stream);
+bool integrate_variant_serves_chains(const KParams& p, int seeding);  // the launch's kernel variant carries the server code
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);

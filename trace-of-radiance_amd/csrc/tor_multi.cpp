@@ -176,6 +176,237 @@ int shard_max_rows(int32_t nrows, int32_t row_tile, int32_t count) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// the three legs of the framebuffer gather, each complete in itself: on TOR_OK canvas holds the frame
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_last_note;
+
+// TOR_FAULT_INJECT = comma list of rccl_init | rccl_xfer | peer: the named leg fails at that point (tests of the fallback
+// chain; on a 1-GPU box `rccl_init` also makes AUTO consider RCCL for a device list with repeated ordinals)
+struct FaultInjection { bool rccl_init = false, rccl_xfer = false, peer = false; };
+FaultInjection fault_injection() {
+  FaultInjection f;
+  if (const char* e = std::getenv("TOR_FAULT_INJECT")) {
+    f.rccl_init = std::strstr(e, "rccl_init") != nullptr;
+    f.rccl_xfer = std::strstr(e, "rccl_xfer") != nullptr;
+    f.peer = std::strstr(e, "peer") != nullptr;
+  }
+  return f;
+}
+
+std::map<std::vector<int>, bool> g_rccl_bad;  // device lists whose single-process communicator failed (guarded by g_comm_mutex)
+bool rccl_known_bad(const std::vector<int>& key) {
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  return g_rccl_bad.count(key) != 0;
+}
+void mark_rccl_bad(const std::vector<int>& key) {
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  g_rccl_bad[key] = true;
+}
+
+const char* gather_name(int m) { return m == TOR_GATHER_RCCL ? "rccl" : (m == TOR_GATHER_PEER ? "peer" : "host"); }
+
+struct GatherJob {
+  const std::vector<TorContext*>* ctxs = nullptr;
+  const std::vector<std::vector<int32_t>>* rows = nullptr;
+  std::vector<int> key;
+  size_t row_bytes = 0;
+  int32_t nrows = 0, ncols = 0, row_tile = 1;
+  int max_rows = 0;
+  char* canvas = nullptr;
+  int n() const { return (int)ctxs->size(); }
+  size_t slot_bytes() const { return (size_t)(max_rows > 0 ? max_rows : 1) * (row_bytes > 0 ? row_bytes : 24); }
+  size_t shard_bytes(int k) const { return (*rows)[(size_t)k].size() * row_bytes; }
+};
+
+// root buffers + de-interleave + D2H, shared by the two device-side legs (the shards already sit in root->gather)
+int assemble_and_download(const GatherJob& j) {
+  TorContext* root = (*j.ctxs)[0];
+  HIP_TRY(hipSetDevice(root->device));
+  HIP_TRY(launch_gather_rows((const double*)root->gather.ptr, (double*)root->frame.ptr, j.nrows, j.ncols, j.row_tile, j.n(),
+                             (long long)(j.slot_bytes() / 8), root->stream));
+  return download_rows(root, root->frame.ptr, j.nrows, j.row_bytes, nullptr, j.canvas, root->stream);
+}
+
+int ensure_root_buffers(const GatherJob& j) {
+  TorContext* root = (*j.ctxs)[0];
+  HIP_TRY(hipSetDevice(root->device));
+  HIP_TRY(root->gather.ensure(j.slot_bytes() * (size_t)j.n()));
+  HIP_TRY(root->frame.ensure((size_t)(j.nrows > 0 ? j.nrows : 1) * (j.row_bytes > 0 ? j.row_bytes : 24)));
+  return TOR_OK;
+}
+
+// hipMemcpyPeerAsync over xGMI.  Peer access is switched on once per (root, peer) pair when the pair supports it -- the
+// copy is then a direct xGMI transfer; without it the runtime stages through the host (still correct, noted).
+int gather_peer(const GatherJob& j, const FaultInjection& fault) {
+  if (fault.peer) return fail(TOR_ERR_HIP, "TOR_FAULT_INJECT=peer");
+  int rc = ensure_root_buffers(j);
+  if (rc != TOR_OK) return rc;
+  TorContext* root = (*j.ctxs)[0];
+  char* gbase = (char*)root->gather.ptr;
+  static std::mutex peer_mutex;
+  static std::map<std::pair<int, int>, bool> peer_enabled;
+  for (int k = 0; k < j.n(); ++k) {
+    TorContext* c = (*j.ctxs)[(size_t)k];
+    const size_t bytes = j.shard_bytes(k);
+    if (bytes == 0) continue;
+    if (c->device == root->device) {
+      HIP_TRY(hipMemcpyAsync(gbase + (size_t)k * j.slot_bytes(), c->scratch.ptr, bytes, hipMemcpyDeviceToDevice, root->stream));
+      continue;
+    }
+    {
+      std::lock_guard<std::mutex> lock(peer_mutex);
+      const std::pair<int, int> pr(root->device, c->device);
+      if (!peer_enabled.count(pr)) {
+        int can = 0;
+        bool on = false;
+        if (hipDeviceCanAccessPeer(&can, root->device, c->device) == hipSuccess && can) {
+          const hipError_t e = hipDeviceEnablePeerAccess(c->device, 0);  // current device = root (set by ensure_root_buffers)
+          on = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+          (void)hipGetLastError();
+        }
+        peer_enabled[pr] = on;
+      }
+    }
+    HIP_TRY(hipMemcpyPeerAsync(gbase + (size_t)k * j.slot_bytes(), root->device, c->scratch.ptr, c->device, bytes, root->stream));
+  }
+  return assemble_and_download(j);
+}
+
+// no device-side gather: every device copies its rows straight into the canvas over its own PCIe link
+int gather_host(const GatherJob& j) {
+  const int N = j.n();
+  std::vector<int> rcs((size_t)N, TOR_OK);
+  std::vector<std::string> errs((size_t)N);
+  auto one = [&](int k) {
+    TorContext* c = (*j.ctxs)[(size_t)k];
+    rcs[(size_t)k] = download_rows(c, c->scratch.ptr, (int64_t)(*j.rows)[(size_t)k].size(), j.row_bytes, (*j.rows)[(size_t)k].data(),
+                                   j.canvas, c->stream);
+    if (rcs[(size_t)k] != TOR_OK) errs[(size_t)k] = tor_last_error();
+  };
+  std::vector<std::thread> pool;
+  for (int k = 1; k < N; ++k) pool.emplace_back(one, k);
+  one(0);
+  for (std::thread& t : pool) t.join();
+  for (int k = 0; k < N; ++k)
+    if (rcs[(size_t)k] != TOR_OK) return fail(rcs[(size_t)k], "device " + std::to_string((*j.ctxs)[(size_t)k]->device) + ": " + errs[(size_t)k]);
+  return TOR_OK;
+}
+
+// One grouped send/recv gather over the communicators of a single-process device list.  EVERY path out of here
+// closes the group and leaves all streams idle: an open group or a half-enqueued transfer would hang the next call.
+int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<TorContext*>& ctxs, const std::vector<const void*>& src,
+                      const std::vector<size_t>& bytes, char* dst_base, size_t dst_stride, bool inject_failure) {
+  const int N = (int)ctxs.size();
+  TorContext* root = ctxs[0];
+  ncclResult_t first = ncclSuccess;
+  const char* where = "";
+  auto note = [&](ncclResult_t r, const char* w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; where = w; } };
+  ncclResult_t r = api->GroupStart();
+  if (r != ncclSuccess) return fail_rccl(r, "ncclGroupStart");
+  for (int k = 1; k < N && first == ncclSuccess; ++k) {
+    if (bytes[(size_t)k] == 0) continue;
+    if (inject_failure && k == N - 1) { note(ncclInternalError, "TOR_FAULT_INJECT=rccl_xfer"); break; }
+    note(api->Send(src[(size_t)k], bytes[(size_t)k], ncclChar, 0, comms[(size_t)k], ctxs[(size_t)k]->stream), "ncclSend");
+    if (first != ncclSuccess) break;
+    note(api->Recv(dst_base + (size_t)k * dst_stride, bytes[(size_t)k], ncclChar, k, comms[0], root->stream), "ncclRecv");
+  }
+  note(api->GroupEnd(), "ncclGroupEnd");
+  // the sends are complete once the matching receives are; wait for all of it so that the streams are idle either way
+  hipError_t he = hipSuccess;
+  for (int k = 0; k < N; ++k) {
+    hipError_t e = hipSetDevice(ctxs[(size_t)k]->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctxs[(size_t)k]->stream);
+    if (e != hipSuccess && he == hipSuccess) he = e;
+  }
+  (void)hipSetDevice(root->device);
+  if (first != ncclSuccess) return fail_rccl(first, where);
+  if (he != hipSuccess) return fail_hip(he, "RCCL gather: stream synchronisation");
+  return TOR_OK;
+}
+
+// Single-process RCCL (ncclCommInitAll): every device sends its shard to devices[0] over its own xGMI link (7 links
+// in parallel, no ring).  A communicator is trusted only after a SELF-CHECK at creation: every device sends a 4 KB
+// pattern through the very same grouped send/recv code and the root's copy must match byte for byte.
+int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
+  if (fault.rccl_init) return fail(TOR_ERR_HIP, "TOR_FAULT_INJECT=rccl_init");
+  RcclApi* api = rccl();
+  if (!api) return fail(TOR_ERR_HIP, "librccl.so.1 could not be loaded");
+  int rc = ensure_root_buffers(j);
+  if (rc != TOR_OK) return rc;
+  const int N = j.n();
+  const std::vector<TorContext*>& ctxs = *j.ctxs;
+  TorContext* root = ctxs[0];
+  std::vector<ncclComm_t>* comms = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    auto it = g_single_process_comms.find(j.key);
+    if (it == g_single_process_comms.end()) {
+      std::vector<ncclComm_t> c((size_t)N, nullptr);
+      RCCL_TRY(api->CommInitAll(c.data(), N, j.key.data()));
+      // self-check: device k sends kCheck bytes of value (k * 37 + i) & 0xff
+      constexpr size_t kCheck = 4096;
+      std::vector<DeviceBuffer> pat((size_t)N);
+      struct Free { std::vector<DeviceBuffer>& v; ~Free() { for (DeviceBuffer& b : v) b.release(); } } free_pat{pat};
+      std::vector<const void*> src((size_t)N, nullptr);
+      std::vector<size_t> bytes((size_t)N, kCheck);
+      std::vector<unsigned char> host(kCheck);
+      int check = TOR_OK;
+      for (int k = 0; k < N && check == TOR_OK; ++k) {
+        for (size_t i = 0; i < kCheck; ++i) host[i] = (unsigned char)((k * 37 + (int)i) & 0xff);
+        hipError_t e = hipSetDevice(ctxs[(size_t)k]->device);
+        if (e == hipSuccess) e = pat[(size_t)k].ensure(kCheck);
+        if (e == hipSuccess) e = hipMemcpy(pat[(size_t)k].ptr, host.data(), kCheck, hipMemcpyHostToDevice);
+        if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: pattern upload");
+        src[(size_t)k] = pat[(size_t)k].ptr;
+      }
+      DeviceBuffer got;
+      struct FreeOne { DeviceBuffer& b; ~FreeOne() { b.release(); } } free_got{got};
+      if (check == TOR_OK) {
+        hipError_t e = hipSetDevice(root->device);
+        if (e == hipSuccess) e = got.ensure(kCheck * (size_t)N);
+        if (e == hipSuccess) e = hipMemset(got.ptr, 0, kCheck * (size_t)N);
+        if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: receive buffer");
+      }
+      if (check == TOR_OK) check = rccl_group_gather(api, c, ctxs, src, bytes, (char*)got.ptr, kCheck, false);
+      if (check == TOR_OK) {
+        std::vector<unsigned char> back(kCheck * (size_t)N);
+        hipError_t e = hipMemcpy(back.data(), got.ptr, back.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: read back");
+        for (int k = 1; k < N && check == TOR_OK; ++k)
+          for (size_t i = 0; i < kCheck; ++i)
+            if (back[(size_t)k * kCheck + i] != (unsigned char)((k * 37 + (int)i) & 0xff)) {
+              check = fail(TOR_ERR_HIP, "RCCL self-check: rank " + std::to_string(k) + "'s pattern arrived corrupted");
+              break;
+            }
+      }
+      if (check != TOR_OK) {
+        for (ncclComm_t cc : c) if (cc) (void)api->CommDestroy(cc);
+        return check;
+      }
+      it = g_single_process_comms.emplace(j.key, std::move(c)).first;
+    }
+    comms = &it->second;
+  }
+  HIP_TRY(hipSetDevice(root->device));
+  char* gbase = (char*)root->gather.ptr;
+  if (j.shard_bytes(0) > 0)
+    HIP_TRY(hipMemcpyAsync(gbase, root->scratch.ptr, j.shard_bytes(0), hipMemcpyDeviceToDevice, root->stream));
+  std::vector<const void*> src((size_t)N, nullptr);
+  std::vector<size_t> bytes((size_t)N, 0);
+  for (int k = 0; k < N; ++k) { src[(size_t)k] = ctxs[(size_t)k]->scratch.ptr; bytes[(size_t)k] = j.shard_bytes(k); }
+  rc = rccl_group_gather(api, *comms, ctxs, src, bytes, gbase, j.slot_bytes(), fault.rccl_xfer);
+  if (rc != TOR_OK) return rc;
+  return assemble_and_download(j);
+}
+
+}  // namespace
+
+void set_last_note(const std::string& s) { g_last_note = s; }
+const std::string& last_note() { return g_last_note; }
+
 int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList world, int64_t max_depth,
                         const TorOptions& o, double timing_ms[5]) {
   using clk = std::chrono::steady_clock;
@@ -195,11 +426,26 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
     const int rc = default_context(o.devices[k], replica, &ctxs[(size_t)k]);
     if (rc != TOR_OK) return rc;
   }
-  int mode = o.gather;
-  if (mode == TOR_GATHER_AUTO) mode = (distinct && rccl() != nullptr) ? TOR_GATHER_RCCL : TOR_GATHER_PEER;
-  if (mode == TOR_GATHER_RCCL && !distinct)
-    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: TOR_GATHER_RCCL needs distinct devices (one RCCL rank per GPU)");
-  if (mode == TOR_GATHER_RCCL && rccl() == nullptr) return fail(TOR_ERR_HIP, "tor_render: TOR_GATHER_RCCL: librccl.so.1 could not be loaded");
+  // Gather plan.  An explicit mode is tried alone (its failure is the caller's answer).  AUTO walks RCCL -> PEER -> HOST:
+  // every leg only touches canvas->pixels once the whole frame is assembled (or, HOST, overwrites every row), so a leg
+  // that fails part-way is simply followed by the next one -- never a wrong canvas.  RCCL is a candidate of AUTO only when
+  // the ordinals are distinct (one RCCL rank per GPU), librccl loads and the communicator of this device list passed
+  // its self-check (gather_rccl below).
+  const FaultInjection fault = fault_injection();
+  std::vector<int> plan;
+  if (o.gather == TOR_GATHER_AUTO) {
+    const std::vector<int> key(o.devices, o.devices + N);
+    if ((distinct || fault.rccl_init) && (rccl() != nullptr || fault.rccl_init) && !rccl_known_bad(key)) plan.push_back(TOR_GATHER_RCCL);
+    plan.push_back(TOR_GATHER_PEER);
+    plan.push_back(TOR_GATHER_HOST);
+  } else {
+    if (o.gather == TOR_GATHER_RCCL && !distinct)
+      return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: TOR_GATHER_RCCL needs distinct devices (one RCCL rank per GPU)");
+    if (o.gather == TOR_GATHER_RCCL && rccl() == nullptr) return fail(TOR_ERR_HIP, "tor_render: TOR_GATHER_RCCL: librccl.so.1 could not be loaded");
+    plan.push_back(o.gather);
+  }
+  // a plan that starts with HOST downloads inside the per-device jobs (every device over its own PCIe link, in parallel)
+  const int mode = plan[0];
 
   const int32_t nrows = canvas->nrows, ncols = canvas->ncols;
   const size_t row_bytes = (size_t)(ncols > 0 ? ncols : 0) * 24;
@@ -269,62 +515,36 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
   timing_ms[4] = 1.0;
   for (int k = 0; k < N; ++k)
     if (!hit[(size_t)k]) timing_ms[4] = 0.0;
-  if (mode == TOR_GATHER_HOST) return TOR_OK;
+  if (mode == TOR_GATHER_HOST) {
+    set_last_note("gather: host");
+    return TOR_OK;
+  }
 
   // ---- phase 2: the shards travel to devices[0] (xGMI), one de-interleave kernel, one D2H ----------------------
   const clk::time_point t0 = clk::now();
-  TorContext* root = ctxs[0];
-  HIP_TRY(hipSetDevice(root->device));
-  const size_t slot_bytes = (size_t)(max_rows > 0 ? max_rows : 1) * (row_bytes > 0 ? row_bytes : 24);
-  HIP_TRY(root->gather.ensure(slot_bytes * (size_t)N));
-  HIP_TRY(root->frame.ensure((size_t)(nrows > 0 ? nrows : 1) * (row_bytes > 0 ? row_bytes : 24)));
-  char* gbase = (char*)root->gather.ptr;
-  if (mode == TOR_GATHER_PEER) {
-    for (int k = 0; k < N; ++k) {
-      const size_t bytes = rows[(size_t)k].size() * row_bytes;
-      if (bytes == 0) continue;
-      if (ctxs[(size_t)k]->device == root->device)
-        HIP_TRY(hipMemcpyAsync(gbase + (size_t)k * slot_bytes, ctxs[(size_t)k]->scratch.ptr, bytes, hipMemcpyDeviceToDevice, root->stream));
-      else
-        HIP_TRY(hipMemcpyPeerAsync(gbase + (size_t)k * slot_bytes, root->device, ctxs[(size_t)k]->scratch.ptr, ctxs[(size_t)k]->device, bytes,
-                                   root->stream));
+  GatherJob job;
+  job.ctxs = &ctxs;
+  job.rows = &rows;
+  job.row_bytes = row_bytes;
+  job.nrows = nrows;
+  job.ncols = ncols;
+  job.row_tile = o.row_tile;
+  job.max_rows = max_rows;
+  job.key.assign(o.devices, o.devices + N);
+  job.canvas = (char*)canvas->pixels;
+  std::string notes;
+  int rc = TOR_OK;
+  for (size_t leg = 0; leg < plan.size(); ++leg) {
+    const int m = plan[leg];
+    rc = m == TOR_GATHER_RCCL ? gather_rccl(job, fault) : (m == TOR_GATHER_PEER ? gather_peer(job, fault) : gather_host(job));
+    if (rc == TOR_OK) {
+      set_last_note(notes + "gather: " + gather_name(m));
+      break;
     }
-  } else {
-    RcclApi* api = rccl();
-    std::vector<ncclComm_t>* comms = nullptr;
-    {
-      std::lock_guard<std::mutex> lock(g_comm_mutex);
-      std::vector<int> key(o.devices, o.devices + N);
-      auto it = g_single_process_comms.find(key);
-      if (it == g_single_process_comms.end()) {
-        std::vector<ncclComm_t> c((size_t)N, nullptr);
-        RCCL_TRY(api->CommInitAll(c.data(), N, key.data()));
-        it = g_single_process_comms.emplace(key, std::move(c)).first;
-      }
-      comms = &it->second;
-    }
-    // each peer sends over its own link to the root (7 links in parallel, no ring)
-    if (!rows[0].empty())
-      HIP_TRY(hipMemcpyAsync(gbase, root->scratch.ptr, rows[0].size() * row_bytes, hipMemcpyDeviceToDevice, root->stream));
-    RCCL_TRY(api->GroupStart());
-    for (int k = 1; k < N; ++k) {
-      const size_t bytes = rows[(size_t)k].size() * row_bytes;
-      if (bytes == 0) continue;
-      RCCL_TRY(api->Send(ctxs[(size_t)k]->scratch.ptr, bytes, ncclChar, 0, (*comms)[(size_t)k], ctxs[(size_t)k]->stream));
-      RCCL_TRY(api->Recv(gbase + (size_t)k * slot_bytes, bytes, ncclChar, k, (*comms)[0], root->stream));
-    }
-    RCCL_TRY(api->GroupEnd());
-    HIP_TRY(hipSetDevice(root->device));
+    notes += std::string(gather_name(m)) + " failed (" + tor_last_error() + "); ";
+    if (m == TOR_GATHER_RCCL) mark_rccl_bad(job.key);  // AUTO never tries a communicator again that failed once
   }
-  HIP_TRY(launch_gather_rows((const double*)root->gather.ptr, (double*)root->frame.ptr, nrows, ncols, o.row_tile, N,
-                             (long long)(slot_bytes / 8), root->stream));
-  const int rc = download_rows(root, root->frame.ptr, nrows, row_bytes, nullptr, (char*)canvas->pixels, root->stream);
-  if (rc != TOR_OK) return rc;
-  if (mode == TOR_GATHER_RCCL)
-    for (int k = 1; k < N; ++k) {  // the sends are complete once the matching receives are, but leave the streams idle
-      HIP_TRY(hipSetDevice(ctxs[(size_t)k]->device));
-      HIP_TRY(hipStreamSynchronize(ctxs[(size_t)k]->stream));
-    }
+  if (rc != TOR_OK) return fail(rc, "tor_render: framebuffer gather: " + notes);
   timing_ms[2] = ms_since(t0);
   return TOR_OK;
 }
@@ -339,6 +559,8 @@ using tor::fail_hip;
 using tor::fail_rccl;
 
 extern "C" {
+
+const char* tor_last_note(void) { return tor::last_note().c_str(); }
 
 int tor_comm_unique_id(uint8_t id_out[128]) {
   if (!id_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_comm_unique_id: NULL argument");
@@ -407,13 +629,17 @@ int tor_render_gather_device(TorContext* ctx, const TorCamera* cam, int32_t nrow
     } else if (rank == root) {
       const size_t mine = (size_t)tor_shard_rows(nrows, o.row_tile, rank, world, nullptr) * row_bytes;
       if (mine > 0) HIP_TRY(hipMemcpyAsync(gbase + (size_t)rank * slot_bytes, ctx->scratch.ptr, mine, hipMemcpyDeviceToDevice, stream));
+      // (every path closes the group: an open group would swallow the next call's RCCL operations)
       RCCL_TRY(api->GroupStart());
-      for (int k = 0; k < world; ++k) {
+      ncclResult_t first = ncclSuccess;
+      for (int k = 0; k < world && first == ncclSuccess; ++k) {
         if (k == rank) continue;
         const size_t bytes = (size_t)tor_shard_rows(nrows, o.row_tile, k, world, nullptr) * row_bytes;
-        if (bytes > 0) RCCL_TRY(api->Recv(gbase + (size_t)k * slot_bytes, bytes, ncclChar, k, ctx->comm->comm, stream));
+        if (bytes > 0) first = api->Recv(gbase + (size_t)k * slot_bytes, bytes, ncclChar, k, ctx->comm->comm, stream);
       }
-      RCCL_TRY(api->GroupEnd());
+      const ncclResult_t ended = api->GroupEnd();
+      if (first != ncclSuccess) return fail_rccl(first, "ncclRecv (framebuffer gather)");
+      if (ended != ncclSuccess) return fail_rccl(ended, "ncclGroupEnd (framebuffer gather)");
     } else {
       const size_t mine = (size_t)tor_shard_rows(nrows, o.row_tile, rank, world, nullptr) * row_bytes;
       if (mine > 0) RCCL_TRY(api->Send(ctx->scratch.ptr, mine, ncclChar, root, ctx->comm->comm, stream));
