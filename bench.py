@@ -18,8 +18,9 @@ Two timed regions are reported on one GPU, each over the same K steps:
 N > 1 (one process per GPU): image rows are dealt to the ranks round-robin (render.nim:55's `parallelFor row`
 across GPUs), every rank renders its rows, then ONE gather of the row shards to rank 0 over xGMI --
 tor_render_gather_device: RCCL inside the library (falls back to torch.distributed's all_gather, also RCCL,
-if the library's communicator cannot be set up) -- both inside the timed region.  Weak scaling: samples per
-pixel grow with N (spp*N), so every GPU traces the same number of samples as the single-GPU run.
+if the library's communicator cannot be set up) -- both inside the timed region.  STRONG scaling by default: the
+frame -- BASELINE configs[2], 1920x1080x1000 spp, the config the ">= 7x at 8 GPUs" target is quoted on -- is the same
+whatever N (`--scaling weak` multiplies spp by N instead; `--config c4` selects BASELINE configs[3], 3840x2160x4096).
 `python bench.py --gpus N` WITHOUT torchrun drives N devices from one process through the drop-in itself
 (TorOptions.devices): the path a Nim host uses.
 
@@ -58,7 +59,13 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1000, help="samples per pixel per GPU (x N ranks)")
+    ap.add_argument("--spp", type=int, default=1000, help="samples per pixel of the frame (--scaling weak: per GPU, x N ranks)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong (default) = the SAME frame on N GPUs -- BASELINE configs[2] stays 1920x1080x1000 spp, the config the "
+                         ">= 7x at 8 GPUs target is quoted on; weak = spp x N, every GPU traces as many samples as the single-GPU run")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4"], default=None,
+                    help="preset sizes: c1 = BASELINE configs[0] geometry 384x216x100, c2 = configs[1] 1920x1080x100, c3 = configs[2] "
+                         "1920x1080x1000 (default), c4 = configs[3] 3840x2160x4096 (the config BASELINE assigns to 8 GPUs)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seeding", choices=["sample", "pixel"], default="sample")
     ap.add_argument("--arith", choices=["strict", "fused"], default="strict")
@@ -79,20 +86,32 @@ def parse_args():
     ap.add_argument("--aux-steps", type=int, default=3, help="steps of each secondary leg (host canvas, accelerations)")
     ap.add_argument("--gather", choices=["lib", "torch"], default="lib", help="N > 1: framebuffer gather inside the library (RCCL) or torch.distributed")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config:
+        args.width, args.height, args.spp = {"c1": (384, 216, 100), "c2": (1920, 1080, 100), "c3": (1920, 1080, 1000),
+                                             "c4": (3840, 2160, 4096)}[args.config]
+    return args
 
 
-def config_name(W, H, spp_per_gpu, world):
-    """Which BASELINE.json configs[] entry this run is (derived from the sizes, never hard-coded)."""
-    if (W, H) == (1920, 1080) and spp_per_gpu == 100 and world == 1:
-        return "BASELINE configs[1]"
-    if (W, H) == (1920, 1080) and spp_per_gpu == 1000:
-        return "BASELINE configs[2]" + ("" if world == 1 else f" weak-scaled to {world} GPUs")
-    if (W, H) == (3840, 2160) and spp_per_gpu * world == 4096:
-        return "BASELINE configs[3]"
-    if (W, H) == (384, 216) and spp_per_gpu == 100 and world == 1:
-        return "BASELINE configs[0] geometry on the GPU"
-    return "custom size (not a BASELINE config)"
+def frame_spp(args, world):
+    """Samples per pixel of the rendered frame: fixed (strong scaling, default) or x N (weak)."""
+    return args.spp * (max(world, 1) if args.scaling == "weak" else 1)
+
+
+def config_name(W, H, spp, world, scaling="strong"):
+    """Which BASELINE.json configs[] entry this run is (derived from the sizes of the RENDERED frame, never hard-coded)."""
+    tail = "" if world == 1 else (f", the same frame on {world} GPUs (strong scaling)" if scaling == "strong" else
+                                  f" weak-scaled to {world} GPUs ({spp} spp in all)")
+    base_spp = spp if scaling == "strong" else spp // max(world, 1)
+    if (W, H) == (1920, 1080) and base_spp == 100:
+        return "BASELINE configs[1]" + tail
+    if (W, H) == (1920, 1080) and base_spp == 1000:
+        return "BASELINE configs[2]" + tail
+    if (W, H) == (3840, 2160) and spp == 4096:
+        return "BASELINE configs[3]" + ("" if world == 1 else f" on {world} GPUs")
+    if (W, H) == (384, 216) and base_spp == 100:
+        return "BASELINE configs[0] geometry on the GPU" + tail
+    return "custom size (not a BASELINE config)" + tail
 
 
 def git_head():
@@ -302,13 +321,20 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def algorithmic_flops_per_sample(scene, tor, queries_per_sample=2.6022):
+    """SURVEY 8(d)'s formulation: queries/sample x (moving x 35 + static x 23 float64 ops) + 500."""
+    n_obj = len(scene)
+    n_moving = sum(1 for i in range(n_obj) if scene.objects[i].kind == tor.MOVING_SPHERE)
+    return queries_per_sample * (n_moving * OPS_PER_TEST_MOVING + (n_obj - n_moving) * OPS_PER_TEST_STATIC) + OPS_PER_SAMPLE_FIXED
+
+
 def bench_single_process_multi_device(args, tor):
     """`python bench.py --gpus N` without torchrun: ONE process drives N devices through the drop-in itself
     (tor_render_opt with TorOptions.devices: a host thread + stream per device, row-cyclic shards, framebuffer
     gather) -- the path a Nim host takes.  Timed region = SURVEY 8(d): host canvas in, host canvas out."""
     import torch
     H, W, N = args.height, args.width, args.gpus
-    spp = args.spp * N
+    spp = frame_spp(args, N)
     n_dev = max(torch.cuda.device_count(), 1)
     devices = [k % n_dev for k in range(N)]
     scene = tor.random_scene(0xFACADE)
@@ -324,6 +350,7 @@ def bench_single_process_multi_device(args, tor):
         tor.render(cv, cam, scene.list(), args.depth, opt)
     elapsed = time.perf_counter() - t0
     timing = tor.last_render_timing()
+    note = tor.last_note()
     verified = None
     if args.verify:
         one = tor.new_canvas(H, W, spp, 2.2)
@@ -332,18 +359,33 @@ def bench_single_process_multi_device(args, tor):
         verified = bool(np.array_equal(one.pixels, cv.pixels))
         if not verified:
             raise SystemExit("multi-device canvas differs from the single-device canvas")
+    value = H * W * spp * args.steps / elapsed / 1e6
+    # roofline of the whole step (the library's per-device kernel events are not visible through the drop-in): the
+    # algorithmic float64 work of the frame (queries per sample as measured at N = 1) over the step time, against N devices
+    fps = algorithmic_flops_per_sample(scene, tor)
+    tflops = value * 1e6 * fps / 1e12
+    roof = {"bound": "valu_fp64", "kernel": "tor::integrate_kernel on each of the N devices (whole step: render + gather + D2H)",
+            "achieved": round(tflops, 3), "peak": PEAK_FP64_VECTOR_TFLOPS * N, "unit": "TFLOP/s",
+            "frac": round(tflops / (PEAK_FP64_VECTOR_TFLOPS * N), 4), "frac_of_nofma_peak": round(tflops / (PEAK_FP64_NOFMA_TFLOPS * N), 4),
+            "flops_per_sample": round(fps, 1), "traffic": None,
+            "note": "step-level figure; the kernel-level roofline (HIP events, PMC traffic) is the N = 1 line's"}
+    cpu = None
+    if not args.no_cpu_baseline and n_dev == 1:
+        # (every listed ordinal is the same GPU: a 1-GPU box emulating N devices -- the host's cores are free for the baseline)
+        cpu = cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds)
     print(json.dumps({
-        "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(H * W * spp * args.steps / elapsed / 1e6, 2),
+        "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(value, 2),
         "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{config_name(W, H, args.spp, N)}: random_scene seed 0xFACADE (485 objects), {W}x{H}, {spp} spp "
-                               f"({args.spp} per GPU), depth {args.depth}", "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
+        "config": {"workload": f"{config_name(W, H, spp, N, args.scaling)}: random_scene seed 0xFACADE (485 objects), {W}x{H}, {spp} spp, "
+                               f"depth {args.depth}", "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
                    "parallelism": f"ONE process, tor_render_opt with devices={devices}: row tiles of {args.row_tile} dealt to {N} "
-                                  f"device contexts, framebuffer gather inside the library",
+                                  f"device contexts, framebuffer gather inside the library ({note})",
                    "timed_region": "SURVEY 8(d): host canvas in/out (scene cached after the first call)"},
         "last_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
-        "canvas_identical_to_single_device": verified, "roofline": None, "cpu_baseline": None}), flush=True)
+        "canvas_identical_to_single_device": verified, "roofline": roof,
+        "cpu_baseline": cpu if cpu is not None else {"value": None, "note": "reported by the N = 1 line (python bench.py)"}}), flush=True)
 
 
 def main():
@@ -379,7 +421,7 @@ def main():
         return bench_animation(args, tor, torch, dist, world, rank, local_rank)
     if world == 1 and n_gpus > 1:
         return bench_single_process_multi_device(args, tor)
-    spp = args.spp * max(world, 1)  # weak scaling: per-GPU samples fixed
+    spp = frame_spp(args, world)  # strong scaling (default): the frame is the same whatever N
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
     arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
     accel = ACCEL_BITS[args.accel]
@@ -555,10 +597,10 @@ def main():
         result = {
             "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": result_dtype, "data": "synthetic",
-            "config": {"workload": f"{config_name(W, H, args.spp, max(world, 1))}: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
-                                   f"{spp} spp ({args.spp} per GPU), depth {args.depth}",
+            "config": {"workload": f"{config_name(W, H, spp, max(world, 1), args.scaling)}: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
+                                   f"{spp} spp, depth {args.depth}",
                        "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
                        "timed_region": "scene + camera resident in HBM, frame stays on the device (harness contract); "
                                        "SURVEY 8(d)'s host-canvas region is reported beside it as `host_canvas`",
@@ -632,7 +674,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds)
     elif rank == 0:
-        result["cpu_baseline"] = None
+        result["cpu_baseline"] = ({"value": None, "note": "timed at N = 1 only (python bench.py): the ranks of a multi-GPU run keep the host cores busy"}
+                                  if world > 1 else None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -209,8 +209,9 @@ TOR_API int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableL
                            int64_t max_depth, const TorOptions* opt);
 
 /* Host-side cost of the last tor_render / tor_render_opt call on this thread, in milliseconds:
- * out[0] scene upload (0 on a cache hit), out[1] launch + kernels until the device is done, out[2] D2H /
- * gather into canvas->pixels, out[3] whole call.  out[4] = 1 when the scene came from the cache. */
+ * out[0] scene upload (0 on a cache hit), out[1] launch + kernels until the device is done (single device: measured
+ * with HIP events on the call's stream, first launch to last kernel), out[2] the rest of the call's device section:
+ * D2H / gather into canvas->pixels, out[3] whole call.  out[4] = 1 when the scene came from the cache. */
 TOR_API int tor_last_render_timing(double out[5]);
 
 /* Thread-local description of the last failure (never NULL). */
@@ -308,7 +309,8 @@ TOR_API int tor_render_frame_h264(TorContext* ctx, const TorCamera* cam, int32_t
  * the tile sort run before the start event); blocks until the kernel has finished.  samples_out
  * (nullable) = pixel-samples that launch traced.  All launches of one context that may be in flight
  * together must use ONE stream (per-launch state lives in a ring of 64 slots; with statistics enabled
- * launches must not overlap at all). */
+ * launches must not overlap at all): tor_render_device returns TOR_ERR_INVALID_ARGUMENT for a launch on a different
+ * stream while the context's previous launch is still running (use one context per stream for concurrency). */
 TOR_API int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out);
 /* Mean duration (ms) of the integrator kernel over the last `last_n` tor_render_device calls
  * (at most 64 are remembered), from the same per-launch HIP events. */
@@ -337,7 +339,8 @@ TOR_API int tor_last_wave_log(TorContext* ctx, uint64_t* out, int64_t cap_waves)
  * launch), out[3] workgroups that were servers from the start, out[4] push threshold (bounce iterations), out[5] chains
  * served, out[6] pushes of hot chains, out[7] pushes in the tail of the frame; out[8..11] microseconds after the
  * kernel's start at which the work counter ran dry, the last wave left the lane loop, the last hot chain and the last
- * tail chain were finished by a server; out[12], out[13] bounce iterations served for hot / tail chains. */
+ * tail chain were finished by a server; out[12], out[13] bounce iterations served for hot / tail chains; out[14] dedicated
+ * server waves that found nothing to do and turned into lane waves; out[15] the adaptive push threshold at the end. */
 TOR_API int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]);
 /* Debug: the cost probe of the last TOR_SEED_PIXEL launch (it runs from 32 spp on): closest-hit queries per pixel over the
  * probe's samples (2 per pixel; per-sample streams, so only statistically what the frame's samples do), in the shard's

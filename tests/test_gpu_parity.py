@@ -487,7 +487,16 @@ def test_bench_multi_rank_path_on_one_gpu(tor):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["gathered_frame_identical_to_single_process"] is True
-    assert d["scaling"] == "weak" and "8 spp (4 per GPU)" in d["config"]["workload"] and d["value"] > 0
+    # strong scaling is the default: the frame -- and its spp -- do not depend on N
+    assert d["scaling"] == "strong" and "640x360, 4 spp" in d["config"]["workload"] and d["value"] > 0
+    assert d["cpu_baseline"]["value"] is None and "N = 1" in d["cpu_baseline"]["note"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port + 1), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--spp", "4", "--width", "640", "--height", "360", "--scaling", "weak", "--no-stats", "--no-pmc"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "weak" and "640x360, 8 spp" in d["config"]["workload"]
 
 
 def test_f32_filter_extreme_scenes(tor):

@@ -12,7 +12,7 @@ H, W, spp = (int(x) for x in size.split("x"))
 k, N = (int(x) for x in shard.split("/")) if shard else (0, 1)
 rows = len(tor.shard_rows(H, 1, k, N))
 ref = None
-KNOBS = ("TOR_FLOOR_THETA", "TOR_KEY_MODE", "TOR_PROBE_SPP", "TOR_TAIL_REST", "TOR_CHAIN_THETA", "TOR_MIG_FLAGS", "TOR_MIGRATE", "TOR_SRV_K", "TOR_SRV_MIN_FRAC", "TOR_SRV_MAX_FRAC", "TOR_PUSH_THETA", "TOR_TAIL_LANES", "TOR_HOT_FRAC", "TOR_PRIO_SHIFT", "TOR_BLOCKS_PER_CU")
+KNOBS = ("TOR_FLOOR_THETA", "TOR_KEY_MODE", "TOR_PROBE_SPP", "TOR_TAIL_REST", "TOR_CHAIN_THETA", "TOR_MIG_FLAGS", "TOR_MIGRATE", "TOR_SRV_FRAC", "TOR_SRV_PATIENCE_US", "TOR_SRV_MIN_FRAC", "TOR_PUSH_THETA", "TOR_TAIL_LANES", "TOR_HOT_FRAC", "TOR_PRIO_SHIFT", "TOR_BLOCKS_PER_CU")
 for setting in sys.argv[2:]:
     for kn in KNOBS:
         os.environ.pop(kn, None)
@@ -38,5 +38,5 @@ for setting in sys.argv[2:]:
     c = ctx.last_handoff_counters()
     print(f"{spec} [{setting:48s}] step {min(ts):8.2f} ms kernel {min(ks):8.2f} ms  same={bool(torch.equal(ref, buf))} srvWG {c['server_workgroups']:3d} thr {c['push_threshold']:6d} "
           f"hot {c['hot_pushes']:6d} tail {c['tail_pushes']:6d} | ms: dry {c['us_counter_dry'] / 1e3:6.1f} lane_end {c['us_lane_end'] / 1e3:6.1f} hot_done {c['us_hot_done'] / 1e3:6.1f} "
-          f"tail_done {c['us_tail_done'] / 1e3:6.1f} | Mits hot {c['its_hot'] / 1e6:6.2f} tail {c['its_tail'] / 1e6:6.2f}", flush=True)
+          f"tail_done {c['us_tail_done'] / 1e3:6.1f} conv {c['servers_converted']:4d} thr_end {c['push_threshold_end']:6d} | Mits hot {c['its_hot'] / 1e6:6.2f} tail {c['its_tail'] / 1e6:6.2f}", flush=True)
     ctx.close()

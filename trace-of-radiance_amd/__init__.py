@@ -594,7 +594,7 @@ class Context:
         out = (C.c_uint64 * 16)()
         _check(lib().tor_last_handoff_counters(self._h, out))
         names = ("tickets", "pushed", "lane_waves_left", "server_workgroups", "push_threshold", "served", "hot_pushes", "tail_pushes",
-                 "us_counter_dry", "us_lane_end", "us_hot_done", "us_tail_done", "its_hot", "its_tail")
+                 "us_counter_dry", "us_lane_end", "us_hot_done", "us_tail_done", "its_hot", "its_tail", "servers_converted", "push_threshold_end")
         return {k: int(v) for k, v in zip(names, out)}
 
     def last_wave_log(self, cap_waves: int = 16384) -> np.ndarray:

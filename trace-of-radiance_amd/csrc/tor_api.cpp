@@ -108,7 +108,13 @@ static bool parse_device_list(const char* e, TorOptions& o) {
   return o.device_count > 0;
 }
 
+// (why the last valid_options() call said no; the callers put it into tor_last_error)
+thread_local std::string g_options_why;
+const std::string& options_why() { return g_options_why; }
+
 bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
+  g_options_why.clear();
+  auto no = [](const char* why) { g_options_why = why; return false; };
   o = TorOptions{};
   o.struct_size = sizeof(TorOptions);
   o.seeding = TOR_SEED_PIXEL;
@@ -122,42 +128,50 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
   if (opt) {
     if (opt->struct_size == sizeof(TorOptions)) o = *opt;
     else if (opt->struct_size == kV1Size) std::memcpy(&o, opt, kV1Size);
-    else return false;
+    else return no("struct_size is neither sizeof(TorOptions) nor the 32-byte round-1 layout");
     o.struct_size = sizeof(TorOptions);
   } else if (for_drop_in) {
     // tor_render() has the reference's signature and no options: a host that cannot pass TorOptions (the Nim
     // shim of INTEGRATION.md) steers the library through the environment.  None of these changes a pixel.
     o.accel = TOR_ACCEL_BLOCKS | TOR_ACCEL_F32;  // exact accelerations on by default for the drop-in
+    // (a malformed value is an error, not a silent fall-back to one GPU / the default: ADVICE r2)
     if (const char* e = std::getenv("TOR_DEFAULT_ACCEL")) {
       char* endp = nullptr;
       const long v = std::strtol(e, &endp, 10);
       if (endp != e && *endp == 0 && v >= 0 && v <= (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) o.accel = (int32_t)v;
+      else return no("TOR_DEFAULT_ACCEL must be 0, 1, 2 or 3");
     }
     if (const char* e = std::getenv("TOR_DEVICES")) {
       TorOptions t = o;
       if (parse_device_list(e, t)) o = t;
+      else return no("TOR_DEVICES must be \"all\" or a comma list of HIP device ordinals that exist (at most TOR_MAX_DEVICES)");
     }
     if (const char* e = std::getenv("TOR_GATHER")) {
       if (!std::strcmp(e, "rccl")) o.gather = TOR_GATHER_RCCL;
       else if (!std::strcmp(e, "peer")) o.gather = TOR_GATHER_PEER;
       else if (!std::strcmp(e, "host")) o.gather = TOR_GATHER_HOST;
+      else if (!std::strcmp(e, "auto")) o.gather = TOR_GATHER_AUTO;
+      else return no("TOR_GATHER must be auto, rccl, peer or host");
     }
   }
-  if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return false;
-  if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return false;
-  if (o.accel < 0 || o.accel > (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) return false;
-  if (o.shard_count < 1) o.shard_count = 1;
-  if (o.row_tile < 1) o.row_tile = 1;
-  if (o.shard_index < 0 || o.shard_index >= o.shard_count) return false;
-  if (o.device_count < 0 || o.device_count > TOR_MAX_DEVICES) return false;
-  if (o.gather < TOR_GATHER_AUTO || o.gather > TOR_GATHER_HOST) return false;
-  if (o.pixel_kernel < TOR_PIXEL_KERNEL_AUTO || o.pixel_kernel > TOR_PIXEL_KERNEL_WAVE) return false;
+  if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return no("seeding must be TOR_SEED_PIXEL or TOR_SEED_SAMPLE");
+  if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return no("arith must be TOR_ARITH_STRICT or TOR_ARITH_FUSED");
+  if (o.accel < 0 || o.accel > (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) return no("accel holds unknown TOR_ACCEL_* bits");
+  if (o.shard_count < 1) o.shard_count = 1;  // (0 in a zero-initialised struct: whole image, one row per tile)
+  if (o.row_tile == 0) o.row_tile = 1;
+  if (o.row_tile < 0) return no("row_tile must be >= 1");
+  if (o.shard_index < 0 || o.shard_index >= o.shard_count) return no("shard_index must lie in [0, shard_count)");
+  if (o.device_count < 0 || o.device_count > TOR_MAX_DEVICES) return no("device_count must lie in [0, TOR_MAX_DEVICES]");
+  if (o.gather < TOR_GATHER_AUTO || o.gather > TOR_GATHER_HOST) return no("gather must be a TOR_GATHER_* value");
+  if (o.pixel_kernel < TOR_PIXEL_KERNEL_AUTO || o.pixel_kernel > TOR_PIXEL_KERNEL_WAVE) return no("pixel_kernel must be a TOR_PIXEL_KERNEL_* value");
   if (o.device_count > 1) {
-    if (o.shard_count != 1) return false;  // the device list IS the sharding
+    // the device list IS the sharding and the placement: shard_index / shard_count / device stay at their defaults (tor_render.h)
+    if (o.shard_count != 1 || o.shard_index != 0) return no("with a device list, shard_index / shard_count must be left at 0 / 1: entry k renders shard k");
+    if (o.device != -1) return no("with a device list, `device` must be left at -1");
     for (int k = 0; k < o.device_count; ++k)
-      if (o.devices[k] < 0) return false;
+      if (o.devices[k] < 0) return no("negative ordinal in the device list");
   } else if (o.device_count == 1) {
-    if (o.devices[0] < 0) return false;
+    if (o.devices[0] < 0) return no("negative ordinal in the device list");
     o.device = o.devices[0];
   }
   return true;
@@ -189,9 +203,16 @@ int ensure_layouts(TorContext* ctx, int accel) {
   auto build_blocks = [&](int v) -> int {
     if (ctx->accel_built[v]) return TOR_OK;
     build_accel(objs, n, ctx->accel[v], v == 1 ? &ctx->f32 : nullptr);
-    ctx->accel_built[v] = true;
-    if (!ctx->accel[v].available) return TOR_OK;
-    ctx->n_layouts_built += 1;
+    if (!ctx->accel[v].available) {
+      ctx->accel_built[v] = true;  // (built: this scene has no culling layout)
+      return TOR_OK;
+    }
+    // the layout counts as built only once every upload below has succeeded: a failed HIP call leaves it unbuilt (the
+    // next launch tries again) instead of marked-built with null or stale device pointers
+    struct Rollback {
+      TorContext* c; int v; bool ok = false;
+      ~Rollback() { if (!ok) { c->d_accel[v].release(); c->accel[v] = tor::HostAccel{}; } }
+    } rollback{ctx, v};
     auto put = [](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
       hipError_t e = b.ensure(bytes > 0 ? bytes : 8);
       if (e == hipSuccess && bytes > 0) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
@@ -211,6 +232,9 @@ int ensure_layouts(TorContext* ctx, int accel) {
       HIP_TRY(ctx->bnd_ring.ensure(slot_bytes * TorContext::kRing));
     }
     if (slot_bytes > ctx->bnd_slot_bytes) ctx->bnd_slot_bytes = slot_bytes;
+    rollback.ok = true;
+    ctx->accel_built[v] = true;
+    ctx->n_layouts_built += 1;
     return TOR_OK;
   };
   int v32 = want_f32 ? 1 : 0;
@@ -282,13 +306,14 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = std::getenv("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
   if (const char* c = std::getenv("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
   if (const char* c = std::getenv("TOR_MIGRATE")) ctx->mig_mode = std::atoi(c);
-  if (const char* c = std::getenv("TOR_SRV_K")) ctx->srv_k = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_SRV_FRAC")) ctx->srv_frac = (float)std::atof(c);
+  if (const char* c = std::getenv("TOR_SRV_PATIENCE_US")) ctx->srv_patience_us = std::atoi(c);
   if (const char* c = std::getenv("TOR_SRV_MIN_FRAC")) ctx->srv_min_frac = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_SRV_MAX_FRAC")) ctx->srv_max_frac = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_PUSH_THETA")) ctx->push_theta = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_FLOOR_THETA")) ctx->floor_theta = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_CHAIN_THETA")) ctx->chain_theta = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
+  if (const char* c = std::getenv("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
   if (const char* c = std::getenv("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
   if (const char* c = std::getenv("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
   if (const char* c = std::getenv("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
@@ -333,6 +358,7 @@ int tor_context_destroy(TorContext* ctx) {
   ctx->frame.release();
   ctx->staging.release();
   for (hipEvent_t ev : ctx->chunk_events) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_call) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (int i = 0; i < TorContext::kRing; ++i) {
@@ -422,7 +448,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: need nrows >= 2, ncols >= 2, samples_per_pixel >= 1");
   if (max_depth > 0x7fffffff) max_depth = 0x7fffffff;
   TorOptions o;
-  if (!valid_options(opt, o, false)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: bad TorOptions");
+  if (!valid_options(opt, o, false)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: bad TorOptions: " + tor::options_why());
   if (o.device_count > 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: one context renders on one device (device lists: tor_render_opt)");
   hipStream_t stream = (hipStream_t)hip_stream;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -438,6 +464,18 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   // launch must be done
   const int slot = (int)(ctx->launches % TorContext::kRing);
   if (ctx->launches >= TorContext::kRing) HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
+  // One stream per context while launches are in flight (tor_render.h): the per-launch state (work counters, tile
+  // schedule, probe buffer, hand-off queue) is ordered by the stream.  A launch on ANOTHER stream is accepted only once
+  // the previous launch of this context has finished.
+  if (ctx->launches > 0 && ctx->last_stream_valid && ctx->last_stream != hip_stream) {
+    const hipError_t q = hipEventQuery(ctx->ev_stop[ctx->last_slot]);
+    if (q == hipErrorNotReady)
+      return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_device: the previous launch of this context is still running on a different stream -- "
+                                            "launches of one context that may overlap must use ONE stream (or use one context per stream)");
+    if (q != hipSuccess) return fail_hip(q, "hipEventQuery");
+  }
+  ctx->last_stream = hip_stream;
+  ctx->last_stream_valid = true;
   unsigned long long* const slot_counters = (unsigned long long*)ctx->counters.ptr + (size_t)slot * TorContext::kSlotWords;
   HIP_TRY(hipMemsetAsync(slot_counters, 0, TorContext::kSlotWords * sizeof(unsigned long long), stream));
   if (max_depth <= 0 || ctx->n_objects < 0) {
@@ -511,105 +549,122 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       return TOR_OK;
     }
   }
-  {
-    const int rc = tor::ensure_layouts(ctx, o.accel);
-    if (rc != TOR_OK) return rc;
-  }
-  // TOR_ACCEL_F32 layout variant; with TOR_ACCEL_BLOCKS it needs float32 block records (HostAccel::sp32),
-  // otherwise the whole launch stays on the float64 layout
-  int v32 = (o.accel & TOR_ACCEL_F32) ? 1 : 0;
-  if (v32 && (o.accel & TOR_ACCEL_BLOCKS) && ctx->accel[1].available && !ctx->accel[1].sp32) v32 = 0;
-  auto use_layout = [&](const tor::DeviceLayout& L) {
-    p.stat = L.stat;
-    p.mov = L.mov;
-    p.movy = L.movy;
-    p.segs = L.segs;
-    p.cold = L.cold;
-    p.hot32 = L.has_f32 ? L.hot32 : nullptr;
-    p.n_segs = L.n_segs;
+  // Layout configuration of a launch: which device arrays the kernel walks for `accel`, the per-call block bounds and the
+  // LDS staging decision.  A lambda because two launches of one call may use it: the frame's kernel with the caller's
+  // accel bits and -- SEED_PIXEL -- the cost probe, which always runs with both exact accelerations when the scene has
+  // them (it only COUNTS closest-hit queries per pixel; the count does not depend on how the hit is found).
+  auto configure = [&](tor::KParams& q, int accel, std::vector<double>& bnd_host, std::vector<float>& bnd32_host, bool& use_accel, int& stage_wg,
+                       const tor::HostAccel*& hacc_out) -> int {
+    {
+      const int rc = tor::ensure_layouts(ctx, accel);
+      if (rc != TOR_OK) return rc;
+    }
+    // TOR_ACCEL_F32 layout variant; with TOR_ACCEL_BLOCKS it needs float32 block records (HostAccel::sp32),
+    // otherwise the whole launch stays on the float64 layout
+    int v32 = (accel & TOR_ACCEL_F32) ? 1 : 0;
+    if (v32 && (accel & TOR_ACCEL_BLOCKS) && ctx->accel[1].available && !ctx->accel[1].sp32) v32 = 0;
+    auto use_layout = [&](const tor::DeviceLayout& L) {
+      q.stat = L.stat;
+      q.mov = L.mov;
+      q.movy = L.movy;
+      q.segs = L.segs;
+      q.cold = L.cold;
+      q.hot32 = L.has_f32 ? L.hot32 : nullptr;
+      q.n_segs = L.n_segs;
+    };
+    const bool blocks_avail = (accel & TOR_ACCEL_BLOCKS) && ctx->accel_built[v32] && ctx->accel[v32].available;
+    if (!blocks_avail) use_layout(ctx->flat[v32]);
+    for (int k = 0; k < 3; ++k) q.org[k] = ctx->f32.origin[k];
+    q.bnd = nullptr;
+    q.spatial_base = 0;
+    q.shot = nullptr;
+    q.sgrp = nullptr;
+    q.shot_lds_doubles = 0;
+    q.shot_stride = 8;
+    use_accel = false;
+    stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
+    const tor::HostAccel& hacc = ctx->accel[v32];
+    hacc_out = &hacc;
+    if (blocks_avail) {
+      // rays carry the camera's shutter times, or 0 after a metal / dielectric bounce (rays.nim:19)
+      const double t_lo = std::fmin(0.0, std::fmin(cam->shutter_open, cam->shutter_close));
+      const double t_hi = std::fmax(0.0, std::fmax(cam->shutter_open, cam->shutter_close));
+      use_accel = tor::compute_block_bounds(hacc, t_lo, t_hi, bnd_host);
+      if (!use_accel) {  // non-finite ray-time range: brute force over the flat layout
+        const int rc = tor::ensure_layouts(ctx, accel & ~TOR_ACCEL_BLOCKS);
+        if (rc != TOR_OK) return rc;
+        use_layout(ctx->flat[v32]);
+      }
+    }
+    if (use_accel) {
+      use_layout(ctx->d_accel[v32].always);
+      q.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
+      q.spatial_base = (int)hacc.spatial_base;
+      q.n_super = (int)(((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) / tor::kPad);
+      q.two_level = hacc.two_level ? 1 : 0;
+      q.shot = (const double*)ctx->d_accel[v32].hot.ptr;
+      q.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
+      q.shot_stride = hacc.hot_stride;
+      // LDS staging of the compact records next to the per-wave queues (18 KB per workgroup, 160 KB per
+      // CU): see the staging decision below.
+      q.shot32 = nullptr;
+      if (v32 && hacc.sp32) {
+        q.shot32 = (const float*)ctx->d_accel[v32].hot32.ptr;
+        q.shot32_stride = hacc.hot32_stride;
+        q.shot32_block_stride = hacc.hot32_block_stride;
+        q.sp_mc0max = hacc.sp_mc0max; q.sp_dcmax = hacc.sp_dcmax;
+        q.sp_t0 = hacc.sp_t0; q.sp_dt = hacc.sp_dt;
+      }
+      // LDS staging of the block records next to the per-wave queues (10 KB per workgroup in these variants, 160 KB per CU): the
+      // float32 pair records (TOR_ACCEL_F32; survivors are re-tested from the cold records -- staging the float64
+      // records as well measured +2 % at best) or the float64 compact records.  It must fit at this mode's
+      // workgroups/CU, else global loads (through L2).
+      size_t hot_bytes = q.shot32 ? hacc.hot32.size() * 4 : hacc.hot.size() * 8;
+      size_t bnd32_stage_floats = 0;
+      if (q.shot32) {
+        // float32 boxes for the slab tests; on two-level scenes the lanes read the block boxes themselves: stage them
+        q.sp_bmax = tor::block_bounds_f32(bnd_host, ctx->f32.origin, bnd32_host);
+        q.bnd32 = (const float*)((const char*)q.bnd + bnd_host.size() * 8);
+        if (hacc.two_level) bnd32_stage_floats = 8 * ((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad);
+      }
+      const char* st = std::getenv("TOR_STAGE_LDS");
+      const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
+      int& wg = stage_wg;
+      wg = 0;
+      auto fits = [&](size_t bytes, int wgs) {
+        return bytes <= hard_cap && bytes + (size_t)tor::integrate_fixed_lds_bytes(1, q.shot32 != nullptr ? 1 : 0) <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
+      };
+      // Workgroups per CU come first: on the 1601-object animation frames 3 workgroups/CU reading the records through L2
+      // render 2339 Msamples/s, 2 workgroups/CU with the records in LDS 1914.  So the launch keeps its full workgroup count
+      // and stages what fits beside it: the block boxes of a two-level scene first (6.6 KB there; every lane reads 8 of
+      // them per super box it expands), then the block records if there is still room; only a launch whose mode runs at 2
+      // workgroups/CU anyway gets the bigger LDS share.
+      const int full = ctx->max_blocks_per_cu[o.seeding][accel != 0];
+      const bool stage_boxes = q.shot32 && bnd32_stage_floats > 0 && fits(bnd32_stage_floats * 4, full);
+      const size_t box_bytes = stage_boxes ? bnd32_stage_floats * 4 : 0;
+      bool stage_hot = fits(hot_bytes + box_bytes, full);
+      wg = (stage_hot || stage_boxes) ? full : 0;
+      if (!q.shot32 && !stage_hot && full > 2 && fits(hot_bytes, full - 1)) {
+        // (the float64 compact records of TOR_ACCEL_BLOCKS alone are read by every lane for every block it enters: there
+        // one workgroup fewer with the records in LDS wins, 1212 against 1140 Msamples/s on the same frames)
+        stage_hot = true;
+        wg = full - 1;
+      }
+      q.shot_lds_doubles = (stage_hot && !q.shot32) ? (int)hacc.hot.size() : 0;
+      q.shot32_lds_floats = (stage_hot && q.shot32) ? (int)hacc.hot32.size() : 0;
+      q.bnd32_lds_floats = stage_boxes ? (int)bnd32_stage_floats : 0;
+    }
+    return TOR_OK;
   };
-  const bool blocks_avail = (o.accel & TOR_ACCEL_BLOCKS) && ctx->accel_built[v32] && ctx->accel[v32].available;
-  if (!blocks_avail) use_layout(ctx->flat[v32]);
-  for (int k = 0; k < 3; ++k) p.org[k] = ctx->f32.origin[k];
-  p.bnd = nullptr;
-  p.spatial_base = 0;
-  p.shot = nullptr;
-  p.sgrp = nullptr;
-  p.shot_lds_doubles = 0;
-  p.shot_stride = 8;
-  std::vector<double>& bnd_host = ctx->bnd_host[slot];
   bool use_accel = false;
   int stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
-  const tor::HostAccel& hacc = ctx->accel[v32];
-  if (blocks_avail) {
-    // rays carry the camera's shutter times, or 0 after a metal / dielectric bounce (rays.nim:19)
-    const double t_lo = std::fmin(0.0, std::fmin(cam->shutter_open, cam->shutter_close));
-    const double t_hi = std::fmax(0.0, std::fmax(cam->shutter_open, cam->shutter_close));
-    use_accel = tor::compute_block_bounds(hacc, t_lo, t_hi, bnd_host);
-    if (!use_accel) {  // non-finite ray-time range: brute force over the flat layout
-      const int rc = tor::ensure_layouts(ctx, o.accel & ~TOR_ACCEL_BLOCKS);
-      if (rc != TOR_OK) return rc;
-      use_layout(ctx->flat[v32]);
-    }
+  const tor::HostAccel* hacc_p = nullptr;
+  {
+    const int rc = configure(p, o.accel, ctx->bnd_host[slot], ctx->bnd32_host[slot], use_accel, stage_wg, hacc_p);
+    if (rc != TOR_OK) return rc;
   }
-  if (use_accel) {
-    use_layout(ctx->d_accel[v32].always);
-    p.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
-    p.spatial_base = (int)hacc.spatial_base;
-    p.n_super = (int)(((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) / tor::kPad);
-    p.two_level = hacc.two_level ? 1 : 0;
-    p.shot = (const double*)ctx->d_accel[v32].hot.ptr;
-    p.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
-    p.shot_stride = hacc.hot_stride;
-    // LDS staging of the compact records next to the per-wave queues (18 KB per workgroup, 160 KB per
-    // CU): see the staging decision below.
-    p.shot32 = nullptr;
-    if (v32 && hacc.sp32) {
-      p.shot32 = (const float*)ctx->d_accel[v32].hot32.ptr;
-      p.shot32_stride = hacc.hot32_stride;
-      p.shot32_block_stride = hacc.hot32_block_stride;
-      p.sp_mc0max = hacc.sp_mc0max; p.sp_dcmax = hacc.sp_dcmax;
-      p.sp_t0 = hacc.sp_t0; p.sp_dt = hacc.sp_dt;
-    }
-    // LDS staging of the block records next to the per-wave queues (10 KB per workgroup in these variants, 160 KB per CU): the
-    // float32 pair records (TOR_ACCEL_F32; survivors are re-tested from the cold records -- staging the float64
-    // records as well measured +2 % at best) or the float64 compact records.  It must fit at this mode's
-    // workgroups/CU, else global loads (through L2).
-    size_t hot_bytes = p.shot32 ? hacc.hot32.size() * 4 : hacc.hot.size() * 8;
-    size_t bnd32_stage_floats = 0;
-    if (p.shot32) {
-      // float32 boxes for the slab tests; on two-level scenes the lanes read the block boxes themselves: stage them
-      p.sp_bmax = tor::block_bounds_f32(bnd_host, ctx->f32.origin, ctx->bnd32_host[slot]);
-      p.bnd32 = (const float*)((const char*)p.bnd + bnd_host.size() * 8);
-      if (hacc.two_level) bnd32_stage_floats = 8 * ((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad);
-    }
-    const char* st = std::getenv("TOR_STAGE_LDS");
-    const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
-    int& wg = stage_wg;
-    wg = 0;
-    auto fits = [&](size_t bytes, int wgs) {
-      return bytes <= hard_cap && bytes + (size_t)tor::integrate_fixed_lds_bytes(1, p.shot32 != nullptr ? 1 : 0) <= (size_t)(160 * 1024) / (size_t)wgs - 1024;
-    };
-    // Workgroups per CU come first: on the 1601-object animation frames 3 workgroups/CU reading the records through L2
-    // render 2339 Msamples/s, 2 workgroups/CU with the records in LDS 1914.  So the launch keeps its full workgroup count
-    // and stages what fits beside it: the block boxes of a two-level scene first (6.6 KB there; every lane reads 8 of
-    // them per super box it expands), then the block records if there is still room; only a launch whose mode runs at 2
-    // workgroups/CU anyway gets the bigger LDS share.
-    const int full = ctx->max_blocks_per_cu[o.seeding][o.accel != 0];
-    const bool stage_boxes = p.shot32 && bnd32_stage_floats > 0 && fits(bnd32_stage_floats * 4, full);
-    const size_t box_bytes = stage_boxes ? bnd32_stage_floats * 4 : 0;
-    bool stage_hot = fits(hot_bytes + box_bytes, full);
-    wg = (stage_hot || stage_boxes) ? full : 0;
-    if (!p.shot32 && !stage_hot && full > 2 && fits(hot_bytes, full - 1)) {
-      // (the float64 compact records of TOR_ACCEL_BLOCKS alone are read by every lane for every block it enters: there
-      // one workgroup fewer with the records in LDS wins, 1212 against 1140 Msamples/s on the same frames)
-      stage_hot = true;
-      wg = full - 1;
-    }
-    p.shot_lds_doubles = (stage_hot && !p.shot32) ? (int)hacc.hot.size() : 0;
-    p.shot32_lds_floats = (stage_hot && p.shot32) ? (int)hacc.hot32.size() : 0;
-    p.bnd32_lds_floats = stage_boxes ? (int)bnd32_stage_floats : 0;
-  }
+  const tor::HostAccel& hacc = *hacc_p;
+  std::vector<double>& bnd_host = ctx->bnd_host[slot];
   // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
   // kernel variant's register budget follows it
   int cap = ctx->max_blocks_per_cu[o.seeding][o.accel != 0];
@@ -683,6 +738,22 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     HIP_TRY(tile_order.ensure((size_t)n_tiles * 4));
     HIP_TRY(hipMemsetAsync(tile_cost.ptr, 0, (size_t)npix * 4, stream));
     tor::KParams pp = p;
+    if (ctx->probe_accel && (o.accel & TOR_ACCEL_BLOCKS) == 0) {
+      // The probe only counts closest-hit queries per pixel -- the count does not depend on how a hit is found -- so a launch
+      // without the block culling (whose ring slot of block bounds is free) still probes with both exact accelerations when
+      // the scene has them: 2.5 ms instead of 7.7 ms in front of a float64 brute-force 1080p frame.
+      tor::KParams pa = p;
+      bool pa_accel = false;
+      int pa_stage = 0;
+      const tor::HostAccel* pa_h = nullptr;
+      const int rc = configure(pa, TOR_ACCEL_BLOCKS | TOR_ACCEL_F32, ctx->probe_bnd_host[slot], ctx->probe_bnd32_host[slot], pa_accel, pa_stage, pa_h);
+      if (rc != TOR_OK) return rc;
+      if (pa_accel && pa.shot32 != nullptr && pa.bnd32 != nullptr) {
+        HIP_TRY(hipMemcpyAsync((void*)pa.bnd, ctx->probe_bnd_host[slot].data(), ctx->probe_bnd_host[slot].size() * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync((void*)pa.bnd32, ctx->probe_bnd32_host[slot].data(), ctx->probe_bnd32_host[slot].size() * 4, hipMemcpyHostToDevice, stream));
+        pp = pa;
+      }
+    }
     pp.spp = ctx->probe_spp;
     pp.total_work = (unsigned long long)npix * (unsigned long long)ctx->probe_spp;
     ctx->last_probe_pixels = npix;
@@ -745,12 +816,12 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       p.mig_cap = (unsigned)cap;
       p.mig_tail_lanes = ctx->mig_tail_lanes;
       p.mig_flags = ctx->mig_flags;
+      p.mig_patience = (unsigned)(ctx->srv_patience_us > 0 ? ctx->srv_patience_us : 0) * 100u;
       p.mig_tail_rest = ctx->mig_tail_rest;
       ms.mig = p.mig;
       ms.lavg_scale = (float)spp / (float)ctx->probe_spp / ((float)blocks * (float)tor::kThreads);
-      ms.srv_k = ctx->srv_k;
+      ms.srv_frac = ctx->srv_frac;
       ms.srv_min_frac = ctx->srv_min_frac;
-      ms.srv_max_frac = ctx->srv_max_frac;
       ms.push_theta = ctx->push_theta;
       ms.chain_scale = (float)spp / (float)ctx->probe_spp / (float)npix;
       ms.chain_theta = ctx->chain_theta;
@@ -956,7 +1027,7 @@ int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]) {
   const unsigned long long t0 = h[tor::kMigT0];
   auto us = [&](unsigned long long t) { return (t == 0 || t == ~0ull || t < t0) ? 0ull : (t - t0) / 100ull; };
   out[8] = us(h[tor::kMigTCounterDry]); out[9] = us(h[tor::kMigTLaneEnd]); out[10] = us(h[tor::kMigTHotDone]); out[11] = us(h[tor::kMigTTailDone]);
-  out[12] = h[tor::kMigItsHot]; out[13] = h[tor::kMigItsTail]; out[14] = 0; out[15] = 0;
+  out[12] = h[tor::kMigItsHot]; out[13] = h[tor::kMigItsTail]; out[14] = h[tor::kMigConverted]; out[15] = h[tor::kMigPushNow];
   return TOR_OK;
 }
 
@@ -1009,7 +1080,7 @@ int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList worl
   const clk::time_point t_call = clk::now();
   if (!canvas || !cam || !canvas->pixels) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: NULL argument");
   TorOptions o;
-  if (!valid_options(opt, o, true)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: bad TorOptions");
+  if (!valid_options(opt, o, true)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render: bad options: " + tor::options_why());
   std::lock_guard<std::mutex> lock(g_render_mutex);
   for (double& t : g_last_timing) t = 0.0;
   if (o.device_count > 1) {
@@ -1047,17 +1118,26 @@ int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList worl
   const int32_t local_rows = tor_shard_rows(nrows, o.row_tile, o.shard_index, o.shard_count, rows.data());
   const size_t row_bytes = (size_t)(ncols > 0 ? ncols : 0) * 24;
   HIP_TRY(ctx->scratch.ensure((size_t)(local_rows > 0 ? local_rows : 1) * (row_bytes > 0 ? row_bytes : 24)));
+  // out[1] ("launch + kernels until the device is done") is measured on the device: one event in front of the launches, one
+  // behind the last kernel; the D2H queues behind them without a host synchronisation in between, and out[2] is the rest
+  // of the section (the part of the download that did not overlap nothing: copies + the host-side row placement)
+  if (!ctx->ev_call[0]) {
+    HIP_TRY(hipEventCreate(&ctx->ev_call[0]));
+    HIP_TRY(hipEventCreate(&ctx->ev_call[1]));
+  }
+  HIP_TRY(hipEventRecord(ctx->ev_call[0], ctx->stream));
   rc = tor_render_device(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction,
                          max_depth, &o, (double*)ctx->scratch.ptr, ctx->stream);
   if (rc != TOR_OK) return rc;
-  const bool want_split = std::getenv("TOR_TIMING_SPLIT") != nullptr;
-  if (want_split) HIP_TRY(hipStreamSynchronize(ctx->stream));  // otherwise the D2H simply queues behind the kernels
-  g_last_timing[1] = ms_since(t0);
-  t0 = clk::now();
+  HIP_TRY(hipEventRecord(ctx->ev_call[1], ctx->stream));
   rc = tor::download_rows(ctx, ctx->scratch.ptr, local_rows, row_bytes, o.shard_count > 1 ? rows.data() : nullptr,
                           (char*)canvas->pixels, ctx->stream);
   if (rc != TOR_OK) return rc;
-  g_last_timing[2] = ms_since(t0);
+  const double section = ms_since(t0);
+  float dev_ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&dev_ms, ctx->ev_call[0], ctx->ev_call[1]));  // (both events are complete: download_rows waited for the stream)
+  g_last_timing[1] = (double)dev_ms < section ? (double)dev_ms : section;
+  g_last_timing[2] = section - g_last_timing[1];
   g_last_timing[3] = ms_since(t_call);
   return TOR_OK;
 }

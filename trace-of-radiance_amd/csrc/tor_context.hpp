@@ -130,6 +130,9 @@ struct TorContext {
   TorCamera cam_host[kRing];                       // host staging must outlive the asynchronous copies
   std::vector<double> bnd_host[kRing];
   std::vector<float> bnd32_host[kRing];
+  std::vector<double> probe_bnd_host[kRing];  // block bounds of the cost probe when it runs with other accel bits than the frame (host staging of an
+  std::vector<float> probe_bnd32_host[kRing];  // asynchronous copy, per ring slot like bnd_host)
+  bool probe_accel = true;  // TOR_PROBE_ACCEL=0: the probe walks the same layout as the frame's kernel
   hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
   int64_t launches = 0;  // timed integrator launches so far
   bool timing_valid = false;
@@ -144,6 +147,9 @@ struct TorContext {
   tor::DeviceBuffer frame;     // ... de-interleaved frame (multi-device tor_render_opt)
   tor::PinnedBuffer staging;   // D2H target
   std::vector<hipEvent_t> chunk_events;
+  hipEvent_t ev_call[2] = {};    // tor_render_opt: around the launches of one call (tor_last_render_timing out[1])
+  void* last_stream = nullptr;   // stream of the last tor_render_device launch (one stream per context while launches overlap)
+  bool last_stream_valid = false;
   hipStream_t stream = nullptr;  // own stream of the host-canvas entry points (created on first use)
   tor::RcclComm* comm = nullptr; // tor_comm_init_rank
   // Launch shape, measured on MI355X (profiles/r1_wave_service.txt): waves that share a SIMD get
@@ -169,11 +175,13 @@ struct TorContext {
   hipEvent_t ev_fork[kRing] = {}, ev_join[kRing] = {};
   // Chain hand-off (SEED_PIXEL with both exact accelerations on a single-level layout, from lpt_min_spp on):
   // lanes push long pixel chains to server waves inside the same launch.  TOR_MIGRATE=0 restores split mode / the
-  // wave-per-pixel kernel.  Knobs: TOR_SRV_K, TOR_SRV_MIN_FRAC, TOR_SRV_MAX_FRAC (dedicated server workgroups =
-  // clamp(srv_k / l_avg, min, max) of the launch), TOR_PUSH_THETA (hand over from theta x l_avg projected bounce
-  // iterations on), TOR_TAIL_LANES.
+  // wave-per-pixel kernel.  Knobs: TOR_SRV_FRAC (share of the workgroups that start as servers when the frame can hold a
+  // chain above the threshold's floor), TOR_SRV_MIN_FRAC (otherwise), TOR_SRV_PATIENCE_US (a dedicated server without work
+  // for that long becomes a lane wave), TOR_PUSH_THETA / TOR_FLOOR_THETA (first value / floor of the adaptive push
+  // threshold, x l_avg), TOR_CHAIN_THETA (floor x the frame's mean chain), TOR_TAIL_LANES, TOR_TAIL_REST, TOR_MIG_FLAGS.
   int mig_mode = 1;
-  float srv_k = 550.0f, srv_min_frac = 0.005f, srv_max_frac = 0.30f, push_theta = 3.0f, chain_theta = 3.5f, floor_theta = 1.33f;
+  float srv_frac = 0.07f, srv_min_frac = 0.005f, push_theta = 3.0f, chain_theta = 3.5f, floor_theta = 1.33f;
+  int srv_patience_us = 8000;
   int key_mode = 1;  // tile sort key of the SEED_PIXEL schedule (TOR_KEY_MODE; tor_kernels.hip tile_key_kernel)
   int mig_tail_lanes = 8;
   int mig_tail_rest = 1024;  // TOR_TAIL_REST
@@ -186,6 +194,7 @@ namespace tor {
 // Options with defaults applied; false when malformed.  `for_drop_in`: NULL options take tor_render()'s
 // environment defaults (TOR_DEFAULT_ACCEL, TOR_DEVICES, TOR_GATHER).
 bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in);
+const std::string& options_why();  // why the last valid_options() call on this thread returned false
 
 // Makes sure the layouts a launch with (accel bits) needs exist on the device (built from scene_bytes).
 int ensure_layouts(TorContext* ctx, int accel);

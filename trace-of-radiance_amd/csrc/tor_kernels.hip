@@ -181,7 +181,7 @@ __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
 
 // chain servers (defined after the kernel): whole waves that continue pixel chains handed over by the lanes
 template <int ARITH>
-__device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated);
+__device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernarg_ptr, int dedicated_arg);
 // which variants carry the hand-off: the reference's streams with both exact accelerations on a single-level layout --
 // what tor_render() runs by default
 constexpr bool migrate_variant(int seeding, int f32, int blocks) { return seeding == 0 && f32 != 0 && blocks == 1; }
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   constexpr bool kMigrate = migrate_variant(SEEDING, F32, BLOCKS);
   const bool mig_on = kMigrate && p.mig != nullptr;
   if (mig_on && threadIdx.x == 0 && blockIdx.x == 0) p.mig[kMigT0] = wall_clock64();
+  if (mig_on && lane == 0) { prof_lds[0] = ~0ull; prof_lds[1] = 0; }  // the wave's copy of the push threshold, bounce counter
   const bool server_only = mig_on && (unsigned long long)blockIdx.x < ((const unsigned long long __attribute__((address_space(4)))*)(uintptr_t)p.mig)[kMigSrvWgs];
   // statistics (tor_last_stats / wave log) live in LDS and are touched only when they were asked for: the
   // kernel is short of scalar registers, counters that are always live would be paid for on every launch
@@ -318,7 +319,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     prof_lds[kSecMark] = now_;                                    \
   }
 
-  for (; !server_only;) {
+  // Roles (hand-off): a dedicated server serves first -- and comes back from there only to become a lane wave (nothing to
+  // serve: a scene without long chains) or because the frame is over; then the lane loop; then every wave serves until
+  // the frame is over.  serve_chains is a real function (noinline, reads KParams through the kernarg segment): inlined, its
+  // registers stayed live across the lane loop and the variant spilled inside the bounce loop.
+  bool lane_role = !server_only;
+  if constexpr (kMigrate) {
+    if (server_only && p.mig_tail_lanes > -2) lane_role = serve_chains<ARITH>((unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr(), 1);
+  }
+  const bool ran_lanes = lane_role;
+  for (; lane_role;) {
     // ================= (A) refill lanes that have no live path =========================
     bool need_fetch = !active && !have_item;
     unsigned long long need_mask = ballot64(need_fetch);
@@ -1367,10 +1377,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         asm volatile("" : "+s"(mq));
         if (mq != nullptr) {
           const bool boundary = ended && have_item;  // a sample just ended and the pixel has more
-          // the adaptive threshold (one relaxed load per wave and bounce; its line is written only by idle servers and pushers)
-          unsigned long long push_at = 0;
-          if (lane == 0) push_at = __hip_atomic_load(mq + kMigPushNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          push_at = bcast_first_u64(push_at);
+          // the adaptive threshold: a per-wave copy in LDS (the debug-counter slots: statistics and hand-off exclude each
+          // other), refreshed from memory every 16th bounce -- thousands of waves reading one line every bounce is traffic the
+          // waiting servers' polls already compete with
+          if (lane == 0) {
+            const unsigned long long n = prof_lds[1];
+            prof_lds[1] = n + 1;
+            if ((n & 15ull) == 0) prof_lds[0] = __hip_atomic_load(mq + kMigPushNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          const unsigned long long push_at = prof_lds[0];
           const bool hot = boundary && s >= 8 && pix_iters >= 64u &&
                            (unsigned long long)pix_iters * (unsigned)p.spp >= push_at * (unsigned)s;
           bool tail_push = boundary && exhausted && !hot && p.mig_tail_lanes >= 0;
@@ -1385,7 +1401,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               }
               hd = bcast_first_u64(hd);
               tl = bcast_first_u64(tl);
-              const unsigned idle = hd > tl ? (unsigned)((hd - tl) > 64ull ? 64ull : (hd - tl)) : 0u;
+              const unsigned idle = hd > tl ? (unsigned)((hd - tl) > 64ull ? 64ull : (hd - tl)) : 0u;  // tickets beyond the last record = waiting servers
               // ... and only chains with a long way to go: a server bounce costs ~10 lane bounces, a short rest is cheaper here
               const unsigned long long rest = (unsigned long long)(unsigned)(p.spp - s) * pix_iters / (unsigned)(s > 0 ? s : 1);
               tail_push = tail_push && rest >= (unsigned long long)p.mig_tail_rest;
@@ -1455,14 +1471,15 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 #undef TOR_SEC
 
   if constexpr (kMigrate) {
-    if (mig_on) {
+    if (mig_on && ran_lanes) {
       // every push of this wave happens-before the decrement: a server that reads 0 here has seen every record
-      if (!server_only && lane == 0) {
+      if (lane == 0) {
         atomicMax(p.mig + kMigTLaneEnd, (unsigned long long)wall_clock64());
         __hip_atomic_fetch_add(p.mig + kMigLaneWaves, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (kPrio && prio_now != 0) __builtin_amdgcn_s_setprio(0);
-      if (p.mig_tail_lanes > -2) serve_chains<ARITH>(p, server_only);  // (TOR_TAIL_LANES=-2: debugging, nobody serves -- only valid when nobody pushes)
+      // (TOR_TAIL_LANES=-2: debugging, nobody serves -- only valid when nobody pushes)
+      if (p.mig_tail_lanes > -2) (void)serve_chains<ARITH>((unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr(), 0);
     }
   }
 
@@ -1795,7 +1812,13 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
 // lane loop and its ticket lies beyond the last record.
 // ---------------------------------------------------------------------------------------------
 template <int ARITH>
-__device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated) {
+__device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernarg_ptr, int dedicated_arg) {
+  // (a real function, not inlined: see the call sites.  Arguments of a device function travel in vector registers; the
+  // kernel hands over the address of its kernarg segment -- KParams is its only argument, at offset 0 -- and the parameters are
+  // read from there through the scalar data path, after the address has been made wave-uniform again)
+  const unsigned long long ka = bcast_first_u64(kernarg_ptr);
+  const __attribute__((address_space(4))) KParams& p = *(const __attribute__((address_space(4))) KParams*)(uintptr_t)ka;
+  const bool dedicated = __builtin_amdgcn_readfirstlane(dedicated_arg) != 0;
   const int lane = threadIdx.x & 63;
   const double w_div = (double)(p.ncols - 1);  // render.nim:64
   const double h_div = (double)(p.nrows - 1);
@@ -1817,28 +1840,48 @@ __device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated) {
     ra0 = c[0]; ra1 = c[1]; ra2 = c[2]; ra3 = c[3]; ra4 = c[4]; ra5 = c[5]; ra7 = c[7]; ra8 = c[8]; ra13 = c[13]; ra14 = c[14]; ra15 = c[15];
   }
   const unsigned long long cap = (unsigned long long)p.mig_cap;
-  const unsigned max_waiting = (unsigned)p.mig_flags >> 16;  // 0: no limit
-  for (;;) {
-    if (max_waiting != 0 && !dedicated) {
-      // enough servers are waiting already: this wave leaves (a waiting wave is not free -- see the wait loop)
-      unsigned long long hd = 0, tl = 0;
+  const unsigned max_naps = (unsigned)(p.mig_flags >> 8) & 0xffu;
+  if (dedicated && p.mig_patience != 0) {
+    // A dedicated server takes no ticket before the first chain has been handed over at all: if none has after
+    // `mig_patience`, this scene has no long chains (no glass) and the wave becomes a lane wave -- counted into kMigLaneWaves
+    // first, and only while that count is not 0 (the frame is still in its lane phase).  Without a ticket it leaves no hole
+    // in the queue.
+    const unsigned long long t_begin = wall_clock64();
+    for (;;) {
+      unsigned long long tl = 0, running = 1;
       if (lane == 0) {
-        hd = __hip_atomic_load(p.mig + kMigHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tl = __hip_atomic_load(p.mig + kMigTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        running = __hip_atomic_load(p.mig + kMigLaneWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      hd = bcast_first_u64(hd);
       tl = bcast_first_u64(tl);
-      if (hd > tl && hd - tl >= (unsigned long long)max_waiting) break;
+      running = bcast_first_u64(running);
+      if (tl != 0 || running == 0) break;  // chains are coming (or the frame is over): serve
+      if (wall_clock64() - t_begin > (unsigned long long)p.mig_patience) {
+        unsigned joined = 0;
+        if (lane == 0) {
+          unsigned long long cur = __hip_atomic_load(p.mig + kMigLaneWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (cur != 0 && !__hip_atomic_compare_exchange_strong(p.mig + kMigLaneWaves, &cur, cur + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {}
+          joined = cur != 0 ? 1u : 0u;
+          if (joined) atomicAdd(p.mig + kMigConverted, 1ull);
+        }
+        if (__builtin_amdgcn_readfirstlane((int)joined) != 0) return true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
     }
+  }
+  for (;;) {
     // ---- take a ticket, wait for its record (or for the end of the frame) ----
     unsigned long long tk = atomicAdd(p.mig + kMigHead, lane == 0 ? 1ull : 0ull);  // (all lanes take part, see coop_pixel_kernel)
     tk = bcast_first_u64(tk);
     bool quit = false;
     // Waiting: poll this ticket's own flag (one lane; the flags of consecutive tickets share a line, waiting servers are
-    // spread over many) with a growing back-off, and look at the end-of-frame words only every 8th poll -- thousands of
-    // waves wait here at the end of a frame and the lanes that still run must not queue behind their traffic.
+    // spread over many) with relaxed loads and a growing back-off, and look at the end-of-frame words only every 8th poll.
+    // An ACQUIRE load here invalidates the CU's vector cache on every poll: with thousands of waves waiting at the end of a
+    // frame the lanes that still ran lost theirs every few hundred ns -- measured 25x slower; a compare-and-swap claim
+    // (instead of tickets) made every waiter hammer one line whenever a chain was pending: the same.
     unsigned polls = 0, naps = 1;
-    const unsigned max_naps = (unsigned)(p.mig_flags >> 8) & 0xffu;
     for (;;) {
       unsigned ready = 0;
       if (lane == 0 && tk < cap) {
@@ -1870,8 +1913,8 @@ __device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated) {
       for (unsigned k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
       if (naps < max_naps) naps *= 2;
     }
+    if (quit) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the record's words were written before the flag was released
-    if (quit) break;
     unsigned long long rec[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) rec[k] = bcast_first_u64(__hip_atomic_load(p.mig_rec + tk * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -2044,6 +2087,7 @@ __device__ __forceinline__ void serve_chains(const KParams& p, bool dedicated) {
       atomicMax(p.mig + (was_hot ? kMigTHotDone : kMigTTailDone), (unsigned long long)wall_clock64());
     }
   }
+  return false;
 }
 
 // Tile schedule for SEED_PIXEL: counting sort of the tiles by probed cost, most expensive first
@@ -2144,8 +2188,12 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, c
     if (sched != nullptr) {
       const unsigned long long front = total - (unsigned long long)((double)tail_frac * (double)lane_work);
       unsigned k_tail = tiles_for(front);
-      if (k_tail < k_split) k_tail = k_split;
       if (k_tail > (unsigned)n_tiles) k_tail = (unsigned)n_tiles;
+      // Region A must not be empty: a slow-slot wave takes from B only while the front waves are still inside A, and with
+      // an empty A (tail_frac >= 1, or a split that takes all of it) no wave would ever fetch B when every wave of the
+      // launch sits in a slow slot -- tiles never rendered.  Then there is no region B: everything is A, and the
+      // slow-slot waves turn into front waves at their first fetch (integrate_kernel: "B ran dry").
+      if (k_tail <= k_split) k_tail = (unsigned)n_tiles;
       sched[0] = (unsigned long long)k_tail * kTilePixels;
       sched[1] = (unsigned long long)k_tail * kTilePixels;
       // hot chains: hot_chain x the probed total, scaled by the host to bounce iterations of the frame
@@ -2154,9 +2202,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, c
     if (mig.mig != nullptr) {
       // Chain hand-off (integrate_kernel / serve_chains).  l_avg = bounce iterations an average lane runs in this frame.
       // The longest chains (glass: ~34 queries per sample whatever the frame) are a fixed number of iterations, so the
-      // smaller l_avg -- a small frame, a row shard of a multi-GPU job -- the larger their share of the frame time and
-      // the more servers must stand ready from the start: dedicated server workgroups = srv_k / l_avg of the launch,
-      // clamped.  A chain is handed over once its projected length exceeds push_theta x l_avg.
+      // smaller l_avg -- a small frame, a row shard of a multi-GPU job -- the larger their share of the frame time.
+      // A chain is handed over once its projected length exceeds the (adaptive) threshold: push_theta x l_avg at first.
       const float l_avg = (float)total * mig.lavg_scale;
       // push threshold: push_theta x l_avg, but never below chain_theta x the frame's MEAN chain -- on a frame with fewer
       // pixels than lanes l_avg says nothing about how long a chain is
@@ -2164,11 +2211,20 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, c
       float push = mig.push_theta * l_avg;
       if (push < mig.chain_theta * mean_chain) push = mig.chain_theta * mean_chain;
       if (push < 64.0f) push = 64.0f;
-      float frac = l_avg > 0.0f ? mig.srv_k / l_avg : mig.srv_max_frac;
-      frac = frac < mig.srv_min_frac ? mig.srv_min_frac : (frac > mig.srv_max_frac ? mig.srv_max_frac : frac);
-      // no chain of this frame can reach the threshold (a sample has at most max_depth queries; the longest chains of a
-      // scene with glass run at ~0.7 of that): nobody will push early, keep the minimum
-      if ((float)mig.spp * 0.7f * (float)mig.max_depth < push) frac = mig.srv_min_frac;
+      // the adaptive threshold starts at `push` and moves between it ... and the length from which a chain cannot finish in a lane
+      // before the frame does (floor_theta x l_avg; same floor from the mean chain as above)
+      float fl = mig.floor_theta * l_avg;
+      if (fl < mig.chain_theta * mean_chain) fl = mig.chain_theta * mean_chain;
+      if (fl < 64.0f) fl = 64.0f;
+      if (fl > push) fl = push;
+      // Dedicated servers.  The share of a frame's work that sits in chains above the threshold is a property of the scene
+      // (glass: ~1 %), and serving it costs 64 x that share x (server bounce / lane bounce = ~3 us / 16 us) of the machine
+      // whatever the frame size: srv_frac of the workgroups start as servers whenever a chain of this frame CAN reach the
+      // threshold at all (a sample has at most max_depth queries; the longest chains of a scene with glass run at ~0.7 of
+      // that).  Servers that find nothing to do turn into lane waves after `mig_patience` (serve_chains), so a scene without
+      // long chains pays ~patience x srv_frac once.
+      float frac = mig.srv_frac;
+      if ((float)mig.spp * 0.7f * (float)mig.max_depth < fl) frac = mig.srv_min_frac;
       int n_srv = (int)(frac * (float)mig.blocks + 0.999f);
       // waves that never get a tile (frames with fewer tiles than waves) are servers from the start anyway
       const int free_wgs = (mig.blocks * (kThreads / 64) - n_tiles) / (kThreads / 64);
@@ -2179,12 +2235,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, c
       mig.mig[kMigSrvWgs] = (unsigned long long)n_srv;
       mig.mig[kMigLaneWaves] = (unsigned long long)(mig.blocks - n_srv) * (kThreads / 64);
       mig.mig[kMigPush] = (unsigned long long)push;
-      // the adaptive threshold starts there and moves between it ... and the length from which a chain cannot finish in a lane
-      // before the frame does (floor_theta x l_avg; same floor from the mean chain as above)
-      float fl = mig.floor_theta * l_avg;
-      if (fl < mig.chain_theta * mean_chain) fl = mig.chain_theta * mean_chain;
-      if (fl < 64.0f) fl = 64.0f;
-      if (fl > push) fl = push;
       mig.mig[kMigPushFloor] = (unsigned long long)fl;
       mig.mig[kMigPushNow] = (unsigned long long)push;
     }

@@ -87,6 +87,7 @@ struct KParams {
   unsigned mig_cap;
   int mig_tail_lanes;           // a wave that has run out of fresh pixels hands its chains over from this many live lanes down
   int mig_tail_rest;            // ... with more live lanes than that: only chains with at least this many bounce iterations to go, and only to idle servers
+  unsigned mig_patience;        // 100 MHz ticks a dedicated server waits without a chain before it turns into a lane wave (0: never)
   unsigned mig_flags;           // bit 0: acquire (not relaxed) polling; bit 1: adaptive push threshold; bits 8-15: longest back-off of a waiting server in naps of ~3.4 us; bits 16-31: at most this many waiting servers (0 = no limit)
   int n_boxes;                  // block boxes of a single-level culling layout (padded to kPad), the servers' first trip
 };
@@ -110,7 +111,8 @@ enum : int {
   kMigItsHot = 71,     // bounce iterations served for hot / tail chains
   kMigItsTail = 72,
   kMigTCounterDry = 73,  // first wave that found the work counter dry
-  kMigPushNow = 80,    // line 5: the ADAPTIVE push threshold (lanes read it every bounce; idle dedicated servers lower it, pushers that meet a backlog raise it)
+  kMigConverted = 74,  // dedicated server waves that turned into lane waves
+  kMigPushNow = 80,    // line 5: the ADAPTIVE push threshold (lanes read it every bounce; idle servers lower it, pushers that meet a backlog raise it)
   kMigWords = 96
 };
 
@@ -123,11 +125,11 @@ hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stre
 int integrate_fixed_lds_bytes(int blocks, int coop);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists)
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
 // schedule of the chain hand-off, computed on the device from the probe's total (tile_order_kernel): l_avg = probed queries x
-// lavg_scale = bounce iterations an average lane runs in this frame; dedicated server workgroups = clamp(srv_k / l_avg, ..) x
-// blocks; push threshold = push_theta x l_avg
+// lavg_scale = bounce iterations an average lane runs in this frame; dedicated server workgroups = srv_frac x blocks when a
+// chain of the frame can reach the threshold's floor (else srv_min_frac); first push threshold = push_theta x l_avg
 struct MigSchedule {
   unsigned long long* mig = nullptr;
-  float lavg_scale = 0.f, srv_k = 0.f, srv_min_frac = 0.f, srv_max_frac = 0.f, push_theta = 0.f;
+  float lavg_scale = 0.f, srv_frac = 0.f, srv_min_frac = 0.f, push_theta = 0.f;
   float chain_scale = 0.f, chain_theta = 0.f, floor_theta = 0.f;  // mean chain of the frame = probed queries x chain_scale; the threshold's floor = chain_theta x that
   int blocks = 0, spp = 0, max_depth = 0;
   int key_mode = 0, probe_spp = 2;  // tile sort key (tile_key_kernel): 0 = longest probed pixel, 1 = certain long chains first, then by the tile's sum

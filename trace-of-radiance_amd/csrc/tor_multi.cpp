@@ -542,7 +542,8 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
       break;
     }
     notes += std::string(gather_name(m)) + " failed (" + tor_last_error() + "); ";
-    if (m == TOR_GATHER_RCCL) mark_rccl_bad(job.key);  // AUTO never tries a communicator again that failed once
+    // AUTO never tries a communicator again that failed once (an injected failure says nothing about the communicator)
+    if (m == TOR_GATHER_RCCL && !fault.rccl_init && !fault.rccl_xfer) mark_rccl_bad(job.key);
   }
   if (rc != TOR_OK) return fail(rc, "tor_render: framebuffer gather: " + notes);
   timing_ms[2] = ms_since(t0);
@@ -600,7 +601,7 @@ int tor_render_gather_device(TorContext* ctx, const TorCamera* cam, int32_t nrow
                              void* hip_stream) {
   if (!ctx || !cam) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_gather_device: NULL argument");
   TorOptions o;
-  if (!tor::valid_options(opt, o, false)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_gather_device: bad TorOptions");
+  if (!tor::valid_options(opt, o, false)) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_gather_device: bad TorOptions: " + tor::options_why());
   const int world = ctx->comm ? ctx->comm->world : 1;
   const int rank = ctx->comm ? ctx->comm->rank : 0;
   if (root >= world) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_gather_device: root out of range");
