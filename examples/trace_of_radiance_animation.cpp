@@ -18,7 +18,7 @@
 int main(int argc, char** argv) {
   const char* path = argc > 1 ? argv[1] : "animation.264";
   const double aspect_ratio = 16.0 / 9.0;                                // :108
-  const int image_width = argc > 2 ? std::atoi(argv[2]) : 256;           // :109 (multiples of 16 everywhere)
+  const int image_width = argc > 2 ? std::atoi(argv[2]) : 256;           // :109 (sizes that are not multiples of 16 are padded and cropped: tor_h264_frame_bytes)
   const int image_height = (int)(image_width / aspect_ratio);            // :110
   const int samples_per_pixel = argc > 3 ? std::atoi(argv[3]) : 10;      // :111
   const float gamma_correction = 2.2f;                                   // :112
@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
   uint8_t header[64];
   const int hn = tor_h264_stream_header(image_width, image_height, header, sizeof header);  // H264Encoder.init
   const int64_t fn = tor_h264_frame_bytes(image_width, image_height);
-  if (hn < 0 || fn < 0) { std::fprintf(stderr, "width and height must be multiples of 16\n"); return 1; }
+  if (hn < 0 || fn < 0) { std::fprintf(stderr, "width and height must be even (4:2:0)\n"); return 1; }
   std::fwrite(header, 1, (size_t)hn, out);
 
   TorOptions opt{};

@@ -279,7 +279,10 @@ TOR_API int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, in
  * device kernel per frame: Canvas -> RGB8 (io/rgb.nim:17-31, top scanline first) -> BT.601 Y'CbCr
  * 4:2:0 (io/color_conversions.nim:180-252) -> one I_PCM slice (io/h264.nim:249-259).
  *   tor_h264_stream_header : SPS (h264.nim:90-142) + PPS (h264.nim:37), written once per stream
- *   tor_h264_frame_bytes   : size of one frame's slice NAL unit (width, height multiples of 16)
+ *   tor_h264_frame_bytes   : size of one frame's slice NAL unit (width, height even; a size that is not a multiple of 16 --
+ *                            1080 rows: BASELINE configs[4] -- is padded to whole macroblocks by edge replication and the SPS
+ *                            crops the padding away (H.264 7.4.2.1.1).  The reference has a TODO there (h264.nim:178): its
+ *                            SPS announces ceil(size/16) macroblocks, its flushFrame writes floor(size/16).)
  *   tor_encode_frame_device: d_pixels = finished canvas (nrows*ncols*3 float64, row 0 = bottom);
  *                            d_slice receives tor_h264_frame_bytes() bytes; d_y/d_cb/d_cr (nullable)
  *                            receive the planes (H264Encoder.getFrameBuffers, h264.nim:206-224).

@@ -231,7 +231,13 @@ def decode_stream(stream: bytes):
         elif t == 5:
             assert sps is not None and pps is not None, "slice before its parameter sets"
             assert sc_len == 4, "B.1.2: zero_byte is required for the first NAL unit of an access unit"
-            pictures.append(decode_idr_ipcm_slice(nal[0], rbsp, sps, pps))
+            h, Y, Cb, Cr = decode_idr_ipcm_slice(nal[0], rbsp, sps, pps)
+            if sps.get("frame_cropping"):   # 7.4.2.1.1, frame_mbs_only, 4:2:0: CropUnitX = CropUnitY = 2 luma samples
+                l, r_, t, b = sps["crop"]
+                Y = Y[2 * t: Y.shape[0] - 2 * b, 2 * l: Y.shape[1] - 2 * r_]
+                Cb = Cb[t: Cb.shape[0] - b, l: Cb.shape[1] - r_]
+                Cr = Cr[t: Cr.shape[0] - b, l: Cr.shape[1] - r_]
+            pictures.append((h, Y, Cb, Cr))
         else:
             raise AssertionError(f"unexpected nal_unit_type {t}")
     return sps, pps, pictures

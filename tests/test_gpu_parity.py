@@ -549,15 +549,24 @@ def test_default_accel_from_environment(tor, monkeypatch):
     accelerations.  Same canvas, and explicit options are never overridden."""
     scene, cam = tor.random_scene(0xFACADE), tor.camera()
 
+    # (a frame above TOR_COOP_MAX_PIXELS, so that tor_render() really runs the accelerated LANE kernel: a small frame takes the
+    # wave-per-pixel kernel, which has no accel variants, and the comparison would test nothing -- ADVICE r2)
+    h, w, spp = 300, 400, 2
+
     def plain():
-        cv = tor.new_canvas(27, 48, 4, 2.2)
+        cv = tor.new_canvas(h, w, spp, 2.2)
         tor.render(cv, cam, scene.list(), 50)            # options=None -> tor_render(), the reference's signature
         return cv.pixels.copy()
     monkeypatch.delenv("TOR_DEFAULT_ACCEL", raising=False)
     base = plain()                                        # unset: both exact accelerations (the drop-in's default)
-    brute = tor.new_canvas(27, 48, 4, 2.2)
-    tor.render(brute, cam, scene.list(), 50, tor.make_options(accel=0))
+    brute = tor.new_canvas(h, w, spp, 2.2)
+    tor.render(brute, cam, scene.list(), 50, tor.make_options(accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE))
     assert np.array_equal(base, brute.pixels)
-    for v in ("0", "3", "2", "1", "17", "x"):
+    for v in ("0", "3", "2", "1"):
         monkeypatch.setenv("TOR_DEFAULT_ACCEL", v)
         assert np.array_equal(plain(), base), v
+    for v in ("17", "x", ""):                             # a malformed value is an error, not a silent default (ADVICE r2)
+        monkeypatch.setenv("TOR_DEFAULT_ACCEL", v)
+        with pytest.raises(tor.TorError) as e:
+            plain()
+        assert e.value.code == -1 and "TOR_DEFAULT_ACCEL" in str(e.value)

@@ -885,15 +885,19 @@ int tor_quantize_rgb8_device(TorContext* ctx, const double* d_pixels, int64_t n_
 // ---- video output stage (io/rgb.nim, io/color_conversions.nim, io/h264.nim) --------------------
 
 int64_t tor_h264_frame_bytes(int32_t width, int32_t height) {
-  if (width < 16 || height < 16 || (width & 15) || (height & 15)) return TOR_ERR_INVALID_ARGUMENT;
-  const int64_t n_mb = (int64_t)(width >> 4) * (height >> 4);
+  // 4:2:0: even sizes.  A size that is not a multiple of 16 is coded with its last macroblock row / column padded by edge
+  // replication and cropped away again by the SPS (tor_h264_stream_header): the standard's way (H.264 7.4.2.1.1).  The
+  // reference has a TODO there (h264.nim:178): its SPS announces ceil(size / 16) macroblocks, its flushFrame writes
+  // floor(size / 16) -- at 1920x1080, BASELINE configs[4]'s size, a stream no decoder accepts.
+  if (width < 2 || height < 2 || (width & 1) || (height & 1) || width > 65520 || height > 65520) return TOR_ERR_INVALID_ARGUMENT;
+  const int64_t n_mb = (int64_t)((width + 15) >> 4) * ((height + 15) >> 4);
   return n_mb * 386 + 8;  // slice header 9 + 384 per macroblock + 2 per macroblock after the first + stop byte
 }
 
 // initSPS (h264.nim:90-142) followed by the constant PPS (h264.nim:37), as H264Encoder.init writes
 // them (h264.nim:174-176).  Returns the number of bytes written or a negative status.
 int tor_h264_stream_header(int32_t width, int32_t height, uint8_t* out, int32_t cap) {
-  if (!out || width < 1 || height < 1) return TOR_ERR_INVALID_ARGUMENT;
+  if (!out || tor_h264_frame_bytes(width, height) < 0) return TOR_ERR_INVALID_ARGUMENT;
   std::vector<uint8_t> b = {0x00, 0x00, 0x00, 0x01};
   unsigned acc = 0;
   int nbits = 0;
@@ -917,7 +921,14 @@ int tor_h264_stream_header(int32_t width, int32_t height, uint8_t* out, int32_t 
   ue(0); put(1, 0);                       // num_ref_frames, gaps_in_frame_num_value_allowed
   ue((unsigned)(((width + 15) >> 4) - 1));
   ue((unsigned)(((height + 15) >> 4) - 1));
-  put(1, 1); put(1, 0); put(1, 0);        // frame_mbs_only, direct_8x8_inference, frame_cropping (never set)
+  put(1, 1); put(1, 0);                   // frame_mbs_only, direct_8x8_inference
+  const unsigned crop_r = (unsigned)((((width + 15) >> 4) << 4) - width) / 2, crop_b = (unsigned)((((height + 15) >> 4) << 4) - height) / 2;
+  if (crop_r == 0 && crop_b == 0) {
+    put(1, 0);                            // frame_cropping_flag: the reference never sets it (h264.nim:178 TODO) -- same bytes for multiples of 16
+  } else {
+    put(1, 1);                            // padded macroblocks are cropped away: offsets in units of 2 luma samples (4:2:0 frames)
+    ue(0); ue(crop_r); ue(0); ue(crop_b);  // left, right, top, bottom
+  }
   put(1, 0); put(1, 1);                   // vui_parameters_present, stop bit
   if (nbits > 0) b.push_back((uint8_t)(acc << (8 - nbits)));
   const uint8_t pps[8] = {0x00, 0x00, 0x00, 0x01, 0x68, 0xce, 0x38, 0x80};
@@ -930,10 +941,10 @@ int tor_h264_stream_header(int32_t width, int32_t height, uint8_t* out, int32_t 
 int tor_encode_frame_device(TorContext* ctx, const double* d_pixels, int32_t nrows, int32_t ncols, uint8_t* d_slice,
                             uint8_t* d_y, uint8_t* d_cb, uint8_t* d_cr, void* hip_stream) {
   if (!ctx || !d_pixels || !d_slice) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_encode_frame_device: NULL argument");
-  // h264.nim:178 "TODO cropping for non-multiple of 16": the reference silently drops the partial
-  // macroblock rows/columns (flushFrame loops over `div 16`); this ABI rejects such frames instead.
+  // h264.nim:178 "TODO cropping for non-multiple of 16": the reference silently drops the partial macroblock rows / columns
+  // (flushFrame loops over `div 16`) although its SPS announces them; here they are padded and cropped (tor_h264_frame_bytes).
   if (tor_h264_frame_bytes(ncols, nrows) < 0)
-    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_encode_frame_device: width and height must be multiples of 16");
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_encode_frame_device: width and height must be even (4:2:0) and at most 65520");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(tor::launch_encode_ipcm(d_pixels, nrows, ncols, d_slice, d_y, d_cb, d_cr, (hipStream_t)hip_stream));
   return TOR_OK;
@@ -947,7 +958,7 @@ int tor_render_frame_h264(TorContext* ctx, const TorCamera* cam, int32_t nrows, 
                           int64_t cap) {
   if (!ctx || !cam || !slice_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: NULL argument");
   const int64_t n = tor_h264_frame_bytes(ncols, nrows);
-  if (n < 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: width and height must be multiples of 16");
+  if (n < 0) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: width and height must be even (4:2:0) and at most 65520");
   if (cap < n) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: output buffer too small");
   if (opt && opt->shard_count > 1) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_render_frame_h264: whole frames only");
   HIP_TRY(hipSetDevice(ctx->device));

@@ -1929,7 +1929,10 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
     const unsigned rtile = lrow / (unsigned)p.row_tile;
     const unsigned within = lrow - rtile * (unsigned)p.row_tile;
     const int row = (int)((rtile * (unsigned)p.shard_count + (unsigned)p.shard_index) * (unsigned)p.row_tile + within);
-    __builtin_amdgcn_s_setprio(3);
+    // arbiter priority while serving: a hot chain is the frame's critical path (level 3); a chain taken over in the tail of the
+    // frame shares its SIMD with lane waves that are finishing theirs (mig_flags bit 2: level 1 then)
+    if (was_hot || !(p.mig_flags & 4u)) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(1);
     for (int s = s_begin; s < p.spp; ++s) {
       // render.nim:64-66
       const double u = ((double)col + uniform01(rng)) / w_div;
@@ -2277,12 +2280,15 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double* pixels, lon
 __global__ __launch_bounds__(256) void encode_ipcm_kernel(const double* pixels, int nrows, int ncols, uint8_t* out,
                                                           uint8_t* plane_y, uint8_t* plane_cb, uint8_t* plane_cr) {
   __shared__ short s_u[256], s_v[256];
-  const int mb_cols = ncols >> 4;
+  const int mb_cols = (ncols + 15) >> 4;
   const int mb = blockIdx.x;
   const int mi = mb / mb_cols, mj = mb - mi * mb_cols;
   const int x = threadIdx.x >> 4, y = threadIdx.x & 15;      // row, column inside the macroblock
   const int vr = mi * 16 + x, vc = mj * 16 + y;              // video row (0 = top), column
-  const double* px = pixels + ((size_t)(nrows - 1 - vr) * ncols + vc) * 3;
+  // a size that is not a multiple of 16: the last macroblock row / column is padded by edge replication (the SPS crops it)
+  const int sr = vr < nrows ? vr : nrows - 1, sc = vc < ncols ? vc : ncols - 1;
+  const bool inside = vr < nrows && vc < ncols;
+  const double* px = pixels + ((size_t)(nrows - 1 - sr) * ncols + sc) * 3;
   int rgb[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -2296,7 +2302,7 @@ __global__ __launch_bounds__(256) void encode_ipcm_kernel(const double* pixels, 
   s_v[threadIdx.x] = (short)(rgb[0] - tY);                            // :222
   const size_t data = 9 + (size_t)mb * 386;                           // first payload byte of this macroblock
   out[data + threadIdx.x] = Y;
-  if (plane_y) plane_y[(size_t)vr * ncols + vc] = Y;
+  if (plane_y && inside) plane_y[(size_t)vr * ncols + vc] = Y;
   __syncthreads();
   if (threadIdx.x < 64) {
     const int cx = threadIdx.x >> 3, cy = threadIdx.x & 7;
@@ -2308,8 +2314,9 @@ __global__ __launch_bounds__(256) void encode_ipcm_kernel(const double* pixels, 
     out[data + 256 + threadIdx.x] = U;
     out[data + 320 + threadIdx.x] = V;
     const size_t cpos = (size_t)(mi * 8 + cx) * (ncols >> 1) + (mj * 8 + cy);
-    if (plane_cb) plane_cb[cpos] = U;
-    if (plane_cr) plane_cr[cpos] = V;
+    const bool cinside = mi * 8 + cx < (nrows >> 1) && mj * 8 + cy < (ncols >> 1);
+    if (plane_cb && cinside) plane_cb[cpos] = U;
+    if (plane_cr && cinside) plane_cr[cpos] = V;
   }
   if (threadIdx.x == 0) {
     if (mb == 0) {  // h264.nim:38: constant slice header (start code, IDR slice NAL, I_PCM first macroblock)
@@ -2450,7 +2457,7 @@ hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* ou
 
 hipError_t launch_encode_ipcm(const double* pixels, int nrows, int ncols, uint8_t* out, uint8_t* plane_y,
                               uint8_t* plane_cb, uint8_t* plane_cr, hipStream_t stream) {
-  const int n_mb = (nrows >> 4) * (ncols >> 4);
+  const int n_mb = ((nrows + 15) >> 4) * ((ncols + 15) >> 4);
   if (n_mb <= 0) return hipSuccess;
   hipLaunchKernelGGL(encode_ipcm_kernel, dim3((unsigned)n_mb), dim3(256), 0, stream, pixels, nrows, ncols, out, plane_y,
                      plane_cb, plane_cr);
