@@ -734,7 +734,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     DeviceBuffer& tile_cost = ctx->probe_buf;
     DeviceBuffer& tile_order = ctx->tile_order[slot];
     // per-pixel query counts of the probe, then per tile: sort key, probed work
-    HIP_TRY(tile_cost.ensure(((size_t)npix + 2 * (size_t)n_tiles) * 4));
+    HIP_TRY(tile_cost.ensure(((size_t)npix + 2 * (size_t)n_tiles) * 4 + tor::kTileSortScratchBytes));
     HIP_TRY(tile_order.ensure((size_t)n_tiles * 4));
     HIP_TRY(hipMemsetAsync(tile_cost.ptr, 0, (size_t)npix * 4, stream));
     tor::KParams pp = p;

@@ -2104,7 +2104,8 @@ constexpr int kCostBins = 4096;
 // glass sphere has a few 27-bounce pixels among sky: by its sum it would start mid-frame and its chains would end the
 // frame) -- with the tile's sum as the tie-breaker; the sum itself is kept for the work accounting of the cuts.
 __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cost, unsigned n_pixels, int n_tiles, unsigned* key,
-                                                        unsigned* work, unsigned key_mode, unsigned probe_spp) {
+                                                        unsigned* work, unsigned key_mode, unsigned probe_spp, unsigned* ghist,
+                                                        unsigned long long* gwork) {
   const int tile = (int)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64);
   if (tile >= n_tiles) return;
   const unsigned pl = (unsigned)tile * kTilePixels + (threadIdx.x & 63);
@@ -2131,6 +2132,10 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cos
       else key[tile] = sum2 < 2047u ? sum2 : 2047u;
     }
     work[tile] = sum > 0 ? sum : 1u;
+    // histogram of the counting sort (tile_order_kernel scans it, tile_scatter_kernel places the tiles): per key, tiles and probed work
+    const unsigned b = key[tile] < (unsigned)kCostBins ? key[tile] : (unsigned)kCostBins - 1;
+    atomicAdd(ghist + b, 1u);
+    atomicAdd(gwork + b, (unsigned long long)(sum > 0 ? sum : 1u));
   }
 }
 
@@ -2142,20 +2147,16 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cos
 //  * tail_frac: the last tiles, carrying tail_frac of the lane kernel's work, form region B of the lane kernel's
 //    schedule: sched[0] = first index of B, sched[1] = B's work counter (started there);
 //  * sched[2] = hot_chain x the probed total: the chain length (bounce iterations) from which a pixel is HOT (priority 3).
-__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, const unsigned* work, unsigned* order, int n_tiles,
+__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* ghist, const unsigned long long* gwork, unsigned* goffs, int n_tiles,
                                                           float split_frac, unsigned long long* split_out,
                                                           unsigned long long* lane_counter, float tail_frac, float hot_chain,
                                                           unsigned long long* sched, const MigSchedule mig) {
+  // (one workgroup, but only over the 4096 bins: the per-tile passes on either side -- histogram in tile_key_kernel, placement
+  // in tile_scatter_kernel -- run on the whole machine; round 2 did all three here in 0.49 ms at 1080p)
   __shared__ unsigned hist[kCostBins];
   __shared__ unsigned offs[kCostBins];
   __shared__ unsigned long long bin_work[kCostBins];
-  for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) { hist[i] = 0; bin_work[i] = 0; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-    const unsigned b = key[i] < (unsigned)kCostBins ? key[i] : (unsigned)kCostBins - 1;
-    atomicAdd(&hist[b], 1u);
-    atomicAdd(&bin_work[b], (unsigned long long)work[i]);
-  }
+  for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) { hist[i] = ghist[i]; bin_work[i] = gwork[i]; }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned run = 0;
@@ -2243,10 +2244,15 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* key, c
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-    const unsigned b = key[i] < (unsigned)kCostBins ? key[i] : (unsigned)kCostBins - 1;
-    order[atomicAdd(&offs[b], 1u)] = (unsigned)i;
-  }
+  for (int i = threadIdx.x; i < kCostBins; i += blockDim.x) goffs[i] = offs[i];
+}
+
+// placement pass of the counting sort: tile i goes to the next free position of its key's range
+__global__ __launch_bounds__(256) void tile_scatter_kernel(const unsigned* key, unsigned* goffs, unsigned* order, int n_tiles) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n_tiles) return;
+  const unsigned b = key[i] < (unsigned)kCostBins ? key[i] : (unsigned)kCostBins - 1;
+  order[atomicAdd(goffs + b, 1u)] = (unsigned)i;
 }
 
 // canvas.nim:47-54
@@ -2392,10 +2398,17 @@ hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
 hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
                              float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
                              float hot_chain, unsigned long long* sched, const MigSchedule& mig, hipStream_t stream) {
+  // sort scratch behind the per-tile arrays (tor_api.cpp sizes the buffer): histogram (tiles, work per key), running offsets
+  unsigned long long* gwork = (unsigned long long*)(((uintptr_t)(work + n_tiles) + 7) & ~(uintptr_t)7);
+  unsigned* ghist = (unsigned*)(gwork + kCostBins);
+  unsigned* goffs = ghist + kCostBins;
+  hipError_t e = hipMemsetAsync(gwork, 0, (size_t)kCostBins * (8 + 4), stream);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, pixel_cost, n_pixels, n_tiles, key, work,
-                     (unsigned)mig.key_mode, (unsigned)(mig.probe_spp > 0 ? mig.probe_spp : 2));
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned*)key, (const unsigned*)work, order, n_tiles, split_frac,
-                     split_out, lane_counter, tail_frac, hot_chain, sched, mig);
+                     (unsigned)mig.key_mode, (unsigned)(mig.probe_spp > 0 ? mig.probe_spp : 2), ghist, gwork);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned*)ghist, (const unsigned long long*)gwork, goffs, n_tiles,
+                     split_frac, split_out, lane_counter, tail_frac, hot_chain, sched, mig);
+  hipLaunchKernelGGL(tile_scatter_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, (const unsigned*)key, goffs, order, n_tiles);
   return hipGetLastError();
 }
 

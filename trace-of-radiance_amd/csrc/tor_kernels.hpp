@@ -139,6 +139,7 @@ hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsi
                              float hot_chain, unsigned long long* sched, const MigSchedule& mig, hipStream_t stream);
 bool integrate_variant_serves_chains(const KParams& p, int seeding);  // the launch's kernel variant carries the server code
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip
+constexpr size_t kTileSortScratchBytes = 4096 * (8 + 4 + 4) + 16;  // launch_tile_order's histogram / offsets behind the per-tile arrays (kCostBins = 4096)
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream);
 hipError_t launch_quantize(const double* pixels, long long n_values, uint8_t* out, hipStream_t stream);
 hipError_t launch_encode_ipcm(const double* pixels, int nrows, int ncols, uint8_t* out, uint8_t* plane_y,
