@@ -181,7 +181,7 @@ __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
 
 // chain servers (defined after the kernel): whole waves that continue pixel chains handed over by the lanes
 template <int ARITH>
-__device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernarg_ptr, int dedicated_arg);
+__device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated);
 // which variants carry the hand-off: the reference's streams with both exact accelerations on a single-level layout --
 // what tor_render() runs by default
 constexpr bool migrate_variant(int seeding, int f32, int blocks) { return seeding == 0 && f32 != 0 && blocks == 1; }
@@ -321,11 +321,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
   // Roles (hand-off): a dedicated server serves first -- and comes back from there only to become a lane wave (nothing to
   // serve: a scene without long chains) or because the frame is over; then the lane loop; then every wave serves until
-  // the frame is over.  serve_chains is a real function (noinline, reads KParams through the kernarg segment): inlined, its
-  // registers stayed live across the lane loop and the variant spilled inside the bounce loop.
+  // the frame is over.  serve_chains is inlined at BOTH places (two copies of its code, no loop around them): as a real
+  // function (noinline) the call's ABI -- reserved scalar registers, stack -- cost the lane loop ~240 more scalar spills
+  // (v_readlane / v_writelane) and 5 % on every frame; inlined once inside a role loop its registers stayed live across the
+  // lane loop (170 spilled VGPRs).
   bool lane_role = !server_only;
   if constexpr (kMigrate) {
-    if (server_only && p.mig_tail_lanes > -2) lane_role = serve_chains<ARITH>((unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr(), 1);
+    if (server_only && p.mig_tail_lanes > -2) lane_role = serve_chains<ARITH>(p, true);
   }
   const bool ran_lanes = lane_role;
   for (; lane_role;) {
@@ -1392,7 +1394,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           bool tail_push = boundary && exhausted && !hot && p.mig_tail_lanes >= 0;
           if (exhausted && p.mig_tail_lanes >= 0) {
             const unsigned live = (unsigned)__builtin_popcountll(ballot64(active || have_item));
-            if (live > (unsigned)p.mig_tail_lanes) {
+            const unsigned long long rest = (unsigned long long)(unsigned)(p.spp - s) * pix_iters / (unsigned)(s > 0 ? s : 1);
+            if (live <= (unsigned)p.mig_tail_lanes) {
+              // the wave's last lanes: hand over what has a way to go; a short rest is finished here (a server bounce costs ~10
+              // lane bounces, and in the tail of a frame the servers are what is scarce)
+              tail_push = tail_push && (rest * 4 >= (unsigned long long)p.mig_tail_rest || live <= 1u);
+            } else {
               // more live lanes than the tail threshold: only as many chains as servers are waiting for one right now
               unsigned long long hd = 0, tl = 0;
               if (lane == 0) {
@@ -1402,8 +1409,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               hd = bcast_first_u64(hd);
               tl = bcast_first_u64(tl);
               const unsigned idle = hd > tl ? (unsigned)((hd - tl) > 64ull ? 64ull : (hd - tl)) : 0u;  // tickets beyond the last record = waiting servers
-              // ... and only chains with a long way to go: a server bounce costs ~10 lane bounces, a short rest is cheaper here
-              const unsigned long long rest = (unsigned long long)(unsigned)(p.spp - s) * pix_iters / (unsigned)(s > 0 ? s : 1);
+              // ... and only chains with a long way to go
               tail_push = tail_push && rest >= (unsigned long long)p.mig_tail_rest;
               const unsigned long long tm = ballot64(tail_push);
               tail_push = tail_push && lane_prefix(tm) < idle;
@@ -1479,7 +1485,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       }
       if (kPrio && prio_now != 0) __builtin_amdgcn_s_setprio(0);
       // (TOR_TAIL_LANES=-2: debugging, nobody serves -- only valid when nobody pushes)
-      if (p.mig_tail_lanes > -2) (void)serve_chains<ARITH>((unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr(), 0);
+      if (p.mig_tail_lanes > -2) (void)serve_chains<ARITH>(p, false);
     }
   }
 
@@ -1812,13 +1818,7 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
 // lane loop and its ticket lies beyond the last record.
 // ---------------------------------------------------------------------------------------------
 template <int ARITH>
-__device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernarg_ptr, int dedicated_arg) {
-  // (a real function, not inlined: see the call sites.  Arguments of a device function travel in vector registers; the
-  // kernel hands over the address of its kernarg segment -- KParams is its only argument, at offset 0 -- and the parameters are
-  // read from there through the scalar data path, after the address has been made wave-uniform again)
-  const unsigned long long ka = bcast_first_u64(kernarg_ptr);
-  const __attribute__((address_space(4))) KParams& p = *(const __attribute__((address_space(4))) KParams*)(uintptr_t)ka;
-  const bool dedicated = __builtin_amdgcn_readfirstlane(dedicated_arg) != 0;
+__device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
   const int lane = threadIdx.x & 63;
   const double w_div = (double)(p.ncols - 1);  // render.nim:64
   const double h_div = (double)(p.nrows - 1);
@@ -1833,12 +1833,6 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
     if (valid1) { const gfptr r = b + 8 * (lane + 64); bx1 = (f2v){r[0], r[1]}; by1 = (f2v){r[2], r[3]}; bz1 = (f2v){r[4], r[5]}; }
   }
   const unsigned n_always = (unsigned)p.spatial_base;
-  // the always-tested objects (cold slots [0, n_always)): lane L keeps record L's fields in registers
-  double ra0 = 0, ra1 = 0, ra2 = 0, ra3 = 0, ra4 = 0, ra5 = 0, ra7 = 0, ra8 = 1.0, ra13 = 0, ra14 = 0, ra15 = -1.0;
-  if ((unsigned)lane < n_always) {
-    const double* c = p.cold + (size_t)lane * 16;
-    ra0 = c[0]; ra1 = c[1]; ra2 = c[2]; ra3 = c[3]; ra4 = c[4]; ra5 = c[5]; ra7 = c[7]; ra8 = c[8]; ra13 = c[13]; ra14 = c[14]; ra15 = c[15];
-  }
   const unsigned long long cap = (unsigned long long)p.mig_cap;
   const unsigned max_naps = (unsigned)(p.mig_flags >> 8) & 0xffu;
   if (dedicated && p.mig_patience != 0) {
@@ -1956,7 +1950,8 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
         const unsigned n_cand = n_always + 8u * (unsigned)(__builtin_popcountll(m0) + __builtin_popcountll(m1));
         const double f_sp = (time - p.sp_t0) / p.sp_dt;  // moving_spheres.nim:42 for the spatial movers' (time0, time1)
         double best_t = __builtin_inf();
-        int best_slot = -1, best_orig = 0x7fffffff;
+        int best_orig = 0x7fffffff, bflags = 0;
+        double bcx = 0, bcy = 0, bcz = 0, b6 = 0, b9 = 0, b10 = 0, b11 = 0, b12 = 0;  // this lane's closest hit: centre, 1/radius, material
         for (unsigned base = 0; base < n_cand; base += 64u) {
           const unsigned i = base + (unsigned)lane;
           int slot = -1;
@@ -1974,17 +1969,13 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
             slot = p.spatial_base + 8 * box + (int)((i - n_always) & 7u);
           }
           if (slot >= 0) {
-            // The record's fields in ONE batch of loads, used without a branch in between: a server's bounce is a chain of
-            // dependent steps, every extra round trip to L2 is paid in full.  (The always-tested objects -- the first
-            // n_always candidates of every query -- sit in registers: ra*.)
+            // The WHOLE record in one batch of loads, used without a branch in between: a server's bounce is a chain of
+            // dependent steps and every extra round trip to L2 is paid in full -- so the fields the shading needs (1/radius,
+            // material) travel with the fields of the test, and the winner's are broadcast from its lane afterwards instead
+            // of being fetched again.
             const double* c = p.cold + (size_t)slot * 16;
-            const bool in_regs = i < n_always && i < 64u;
-            double k0, k1, k2, k3, k4, k5, k7, k8, k13, k14, k15;
-            if (in_regs) {
-              k0 = ra0; k1 = ra1; k2 = ra2; k3 = ra3; k4 = ra4; k5 = ra5; k7 = ra7; k8 = ra8; k13 = ra13; k14 = ra14; k15 = ra15;
-            } else {
-              k0 = c[0]; k1 = c[1]; k2 = c[2]; k3 = c[3]; k4 = c[4]; k5 = c[5]; k7 = c[7]; k8 = c[8]; k13 = c[13]; k14 = c[14]; k15 = c[15];
-            }
+            const double k0 = c[0], k1 = c[1], k2 = c[2], k3 = c[3], k4 = c[4], k5 = c[5], k6 = c[6], k7 = c[7], k8 = c[8];
+            const double k9 = c[9], k10 = c[10], k11 = c[11], k12 = c[12], k13 = c[13], k14 = c[14], k15 = c[15];
             const bool moving = ((int)__double_as_longlong(k13) & 1) != 0;
             double f = f_sp;  // (the spatial movers share one time group: same operands as the division, same quotient)
             if (moving && !(k7 == p.sp_t0 && k8 == p.sp_dt)) f = (time - k7) / k8;
@@ -2014,7 +2005,11 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
               }
               if (ok) {
                 const int orig = (int)__double_as_longlong(k14);
-                if (sol < best_t || (sol == best_t && orig < best_orig)) { best_t = sol; best_slot = slot; best_orig = orig; }
+                if (sol < best_t || (sol == best_t && orig < best_orig)) {
+                  best_t = sol; best_orig = orig;
+                  bcx = cx; bcy = cy; bcz = cz; b6 = k6; b9 = k9; b10 = k10; b11 = k11; b12 = k12;
+                  bflags = (int)__double_as_longlong(k13);
+                }
               }
             }
           }
@@ -2029,22 +2024,22 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
           const int o_min = wave_min_i32(best_t == t_min ? best_orig : 0x7fffffff);
           win = ballot64(best_t == t_min && best_orig == o_min);
         }
-        const int slot = __builtin_amdgcn_readlane(best_slot, (int)__builtin_ctzll(win));
-        // ---- shade: wave-uniform (every lane holds the same values) ----
-        const cdptr c = cold + (size_t)slot * 16;
-        const int flags = (int)__double_as_longlong(c[13]);
-        V3 center = v3(c[0], c[1], c[2]);
-        if (flags & 1) {
-          const double hit_f = (c[7] == p.sp_t0 && c[8] == p.sp_dt) ? f_sp : (time - c[7]) / c[8];
-          if (ARITH == 0) center = center + v3(c[3], c[4], c[5]) * hit_f;
-          else center = v3(fma_(c[3], hit_f, c[0]), fma_(c[4], hit_f, c[1]), fma_(c[5], hit_f, c[2]));
-        }
+        // ---- shade: wave-uniform (every lane holds the same values: the winner's, broadcast from its lane) ----
+        const int wl = (int)__builtin_ctzll(win);
+        auto bc = [&](double v) {
+          const unsigned long long bits = double_to_bits(v);
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, wl), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), wl);
+          return bits_to_double(((unsigned long long)hi << 32) | (unsigned long long)lo);
+        };
+        const V3 center = v3(bc(bcx), bc(bcy), bc(bcz));  // (the centre the test computed: moving_spheres.nim:43 evaluated once)
+        const double c6 = bc(b6), c9 = bc(b9), c10 = bc(b10), c11 = bc(b11), c12 = bc(b12);
+        const int flags = __builtin_amdgcn_readlane(bflags, wl);
         const V3 hp = o + d * t_min;               // rays.nim:24-25
-        const V3 outward = (hp - center) * c[6];   // spheres.nim:43
+        const V3 outward = (hp - center) * c6;     // spheres.nim:43
         const bool front = dot(d, outward) < 0.0;  // core.nim:47-49
         const V3 n = front ? outward : -outward;
         const int mat = (flags >> 8) & 0xff;
-        const V3 albedo = v3(c[9], c[10], c[11]);
+        const V3 albedo = v3(c9, c10, c11);
         bool absorbed = false;
         if (mat == kLambertian) {  // materials.nim:24-30
           d = n + random_unit_vector(rng);
@@ -2052,14 +2047,14 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
           att = mul_att(att, albedo);
         } else if (mat == kMetal) {  // materials.nim:39-47
           const V3 reflected = reflect(unit_vector(d), n);
-          const V3 nd = reflected + random_in_unit_sphere(rng) * c[12];
+          const V3 nd = reflected + random_in_unit_sphere(rng) * c12;
           o = hp;
           d = nd;
           time = 0.0;
           if (dot(nd, n) > 0.0) att = mul_att(att, albedo);
           else absorbed = true;
         } else {  // materials.nim:62-86
-          const double eta = front ? c[9] : c[12];  // 1.0 / ri : ri
+          const double eta = front ? c9 : c12;  // 1.0 / ri : ri
           const V3 ud = unit_vector(d);
           const double dn = dot(-ud, n);
           const double cos_theta = (dn <= 1.0) ? dn : 1.0;
@@ -2068,7 +2063,7 @@ __device__ __attribute__((noinline)) bool serve_chains(unsigned long long kernar
           if (eta * sin_theta > 1.0) {
             nd = reflect(ud, n);
           } else {
-            const double reflect_prob = schlick_r0(cos_theta, front ? c[10] : c[11]);
+            const double reflect_prob = schlick_r0(cos_theta, front ? c10 : c11);
             if (uniform01(rng) < reflect_prob) nd = reflect(ud, n);
             else nd = refract(ud, n, eta);
           }
