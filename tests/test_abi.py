@@ -97,3 +97,38 @@ def test_options_layout_and_versions(tor):
             setattr(o, k, v)
         assert L.tor_render_opt(C.byref(cs), C.byref(cam), scene.list(), 50, C.byref(o)) == -1, bad
     assert L.tor_render_ptr(C.byref(cs), C.byref(cam), None, 50) == -1
+
+
+def test_bad_settings_say_why_before_a_device_is_touched(tor, monkeypatch):
+    """Round 3: malformed TorOptions and TOR_* settings are TOR_ERR_INVALID_ARGUMENT with a reason in
+    tor_last_error() -- never a silent fall-back -- and the check comes before any device work (so it runs here, without a GPU)."""
+    import ctypes as C
+    scene, cam = tor.random_scene(0xFACADE), tor.camera()
+    cv = tor.new_canvas(4, 4, 1, 2.2)
+    cv.pixels[:] = 7.0
+    for kw, word in ((dict(devices=[0, 0], shard_index=1, shard_count=2), "device list"), (dict(devices=[0, 1], device=0), "device"),
+                     (dict(row_tile=-3), "row_tile"), (dict(accel=9), "accel"), (dict(seeding=5), "seeding")):
+        with pytest.raises(tor.TorError) as e:
+            tor.render(cv, cam, scene.list(), 5, tor.make_options(**kw))
+        assert e.value.code == -1 and word in str(e.value), (kw, str(e.value))
+    for name, val in (("TOR_GATHER", "carrier-pigeon"), ("TOR_DEFAULT_ACCEL", "7"), ("TOR_DEFAULT_ACCEL", "x"), ("TOR_DEVICES", "0,abc")):
+        monkeypatch.setenv(name, val)
+        with pytest.raises(tor.TorError) as e:
+            tor.render(cv, cam, scene.list(), 5)            # tor_render(): the settings come from the environment
+        assert e.value.code == -1 and name in str(e.value), (name, str(e.value))
+        monkeypatch.delenv(name)
+    assert np.all(cv.pixels == 7.0)
+    assert tor.last_note() == "" or tor.last_note().startswith("gather:") or "gather" in tor.last_note()
+    out = (C.c_uint64 * 16)()
+    assert tor.lib().tor_last_handoff_counters(None, out) == -1
+
+
+def test_h264_sizes_that_are_not_whole_macroblocks(tor):
+    """Round 3: 1080 rows (BASELINE configs[4]) is 67.5 macroblocks.  Padded + cropped by the SPS (H.264 7.4.2.1.1); odd sizes
+    have no 4:2:0 frame."""
+    assert tor.h264_frame_bytes(1920, 1080) == 120 * 68 * 386 + 8
+    assert tor.h264_frame_bytes(1920, 1088) == 120 * 68 * 386 + 8
+    assert len(tor.h264_stream_header(1920, 1080)) > len(tor.h264_stream_header(1920, 1088))   # frame_cropping_flag + offsets
+    for w, h in ((1921, 1080), (1920, 1081), (0, 0), (-16, 16)):
+        with pytest.raises(tor.TorError):
+            tor.h264_frame_bytes(w, h)

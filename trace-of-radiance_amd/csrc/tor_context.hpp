@@ -184,7 +184,7 @@ struct TorContext {
   int srv_patience_us = 8000;
   int key_mode = 1;  // tile sort key of the SEED_PIXEL schedule (TOR_KEY_MODE; tor_kernels.hip tile_key_kernel)
   int mig_tail_lanes = 8;
-  int mig_tail_rest = 1024;  // TOR_TAIL_REST
+  int mig_tail_rest = 256;   // TOR_TAIL_REST
   unsigned mig_flags = (8u << 8) | 2u | 4u;  // TOR_MIG_FLAGS (tor_kernels.hpp KParams::mig_flags)
   tor::DeviceBuffer mig_rec, mig_flag;
 };
