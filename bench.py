@@ -590,8 +590,11 @@ def main():
             "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 4), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 8),
                     "algorithmic_bytes_per_launch": hbm_bytes},
-            "note": "the path is float64-VALU bound by design (scene in SGPRs via the scalar cache, 24 B of HBM "
-                    "per pixel); the reference's arithmetic has no FMA, so 0.5 of the FMA peak is its ceiling",
+            "note": "the path is float64-VALU bound by design (scene in SGPRs via the scalar cache, 24 B of HBM per pixel).  achieved = "
+                    "samples/s x the reference formulation's float64 operation count (SURVEY 8d).  The reference's arithmetic has no FMA "
+                    "(0.5 of the FMA peak would be its ceiling); the object loop therefore SCREENS every ray x object pair with a "
+                    "conservative FMA form of the same quadratic (11-14 instructions, csrc/tor_screen.hpp) and runs the reference's unfused "
+                    "operations only on the candidates -- same canvas bit for bit (`unscreened` = without it)",
         }
         if args.accel != "none":
             # with an exact acceleration the rate is still quoted against the reference's brute-force
@@ -610,6 +613,9 @@ def main():
             "config": {"workload": f"{config_name(W, H, spp, max(world, 1), args.scaling)}: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
                                    f"{spp} spp, depth {args.depth}",
                        "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
+                       "object_loop": ("every ray x every object in float64; conservative FMA screen, candidates re-tested with the reference's "
+                                       "unfused operations (TOR_SCREEN=0 turns the screen off)") if (args.accel == "none" and args.arith == "strict"
+                                                                                                     and os.environ.get("TOR_SCREEN", "1") != "0") else "see accel / arith",
                        "timed_region": "scene + camera resident in HBM, frame stays on the device (harness contract); "
                                        "SURVEY 8(d)'s host-canvas region is reported beside it as `host_canvas`",
                        "parallelism": f"row tiles of {args.row_tile} dealt to {max(world, 1)} rank(s)" +
@@ -645,6 +651,28 @@ def main():
         # secondary legs (never the metric's value): the same frame with the exact accelerations -- bit-identical
         # canvas (tests/test_gpu_parity.py::test_block_culling_never_changes_a_pixel), checked here again
         ref_frame = frame.clone()
+        if arith == tor.ARITH_STRICT:
+            # the same brute force WITHOUT the conservative FMA screen (csrc/tor_screen.hpp): every object through the
+            # reference's unfused discriminant (rounds 1-2) -- a second context, the knob is read when a context is made
+            os.environ["TOR_SCREEN"] = "0"
+            ctx0 = tor.Context(dev_index)
+            os.environ.pop("TOR_SCREEN", None)
+            ctx0.upload(scene.list())
+            ctx0.render_device(cam, H, W, spp, 2.2, args.depth, opt, frame.data_ptr(), stream)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref_frame, frame))
+            t1 = time.perf_counter()
+            for _ in range(aux):
+                ctx0.render_device(cam, H, W, spp, 2.2, args.depth, opt, frame.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            result["unscreened"] = {
+                "value": round(total_samples * aux / dt2 / 1e6, 2), "unit": "Msamples/s", "steps": aux, "ms_per_step": round(dt2 / aux * 1e3, 3),
+                "canvas_identical_to_value_frame": same,
+                "note": "TOR_SCREEN=0: 17 / 19 / 23 unfused float64 operations per ray x object in the wave-uniform loop (the reference's "
+                        "discriminant as written) instead of the 11 / 12 / 14-instruction conservative FMA screen; candidates get the "
+                        "reference's exact test either way"}
+            ctx0.close()
         notes = {"f32": "every ray x every object, through the conservative packed-float32 pre-filter first "
                         "(tor_filter32.hpp); kept objects get the reference's float64 test",
                  "blocks": "SURVEY 8 f4: spatial blocks of 8 objects behind conservative boxes",

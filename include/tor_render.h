@@ -413,6 +413,13 @@ TOR_API int tor_selftest_filter32_host(int64_t n, const double* o, const double*
                                        const double* dc, const int32_t* moving, const double* f, const double* r2,
                                        const double* origin, int32_t* keep, int32_t* need);
 
+/* The conservative FMA screen of the strict float64 object loop on the HOST (same source as the kernel, csrc/tor_screen.hpp):
+ * ray i against sphere i, margins as for a segment that holds only this object.  keep / need as above; correct iff
+ * need[i] != 0 implies keep[i] != 0.  (The screen only selects candidates for the exact test of spheres.nim:29-48.) */
+TOR_API int tor_selftest_screen_host(int64_t n, const double* o, const double* d, const double* c0,
+                                     const double* dc, const int32_t* moving, const double* f, const double* r2,
+                                     int32_t* keep, int32_t* need);
+
 /* Runs the kernel's own math on the DEVICE: op 0: sin,cos(a)  1: x^5  2: pow(x,y)
  * 3: sqrt(x)  4: x/y  5: uniform01 of seed(row=x,col=y) first n draws... see tests. */
 TOR_API int tor_selftest_math_device(int32_t op, const double* x, const double* y, double* out0,

@@ -4,6 +4,7 @@
  * the multi-GPU path's fallback chain (TOR_FAULT_INJECT), still on one GPU;
  * ABI nits: tor_last_render_timing measured with events, the one-stream-per-context rule, option validation;
  * an empty region A in the SEED_PIXEL schedule with every wave in a slow slot (ADVICE r2);
+ * the conservative FMA screen of the strict float64 object loop (csrc/tor_screen.hpp): on / off, same canvas, == oracle;
  * full-size coverage of the two multi-GPU configs on one GPU: the whole configs[3] frame on one context == its 8 shares
    assembled through the device-list path; configs[4] over 8 consecutive frames through the real frame loop."""
 import ctypes as C
@@ -19,7 +20,7 @@ TOL = 1e-5
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HANDOFF_KNOBS = ("TOR_MIGRATE", "TOR_SRV_FRAC", "TOR_SRV_MIN_FRAC", "TOR_SRV_PATIENCE_US", "TOR_PUSH_THETA", "TOR_CHAIN_THETA", "TOR_FLOOR_THETA",
-                 "TOR_TAIL_LANES", "TOR_TAIL_REST", "TOR_MIG_FLAGS", "TOR_KEY_MODE", "TOR_BACK_SLOT", "TOR_TAIL_FRAC", "TOR_PROBE_ACCEL")
+                 "TOR_TAIL_LANES", "TOR_TAIL_REST", "TOR_MIG_FLAGS", "TOR_KEY_MODE", "TOR_BACK_SLOT", "TOR_TAIL_FRAC", "TOR_PROBE_ACCEL", "TOR_SCREEN")
 
 
 def _exact(got, want):
@@ -319,3 +320,75 @@ def test_configs4_frame_loop_over_eight_frames(tor, oracle):
         assert 16 <= int(y.min()) and int(y.max()) <= 235       # limited-range BT.601 luma
     for c in ctxs:
         c.close()
+
+
+def _screen_scenes(tor):
+    """(name, scene, camera): the bench scene; objects of every kind in three time groups around a big glass sphere, seen
+    through a lens; the bench scene from INSIDE the cloud; the bench scene moved 3e5 units away from the origin (o - c cancels
+    11 digits: the reference's own discriminant is noise at the 1e-6 level there, and so are the screen's margins)."""
+    rng = np.random.default_rng(5)
+    recs = [[0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0]]
+    for i in range(120):
+        x, z = rng.uniform(-9, 9, 2)
+        kind, mat = i % 4, [0, 1, 2][i % 3]
+        r = 0.25 if i % 17 else -0.25
+        if kind == 0:
+            recs.append([0, x, .25, z, x, .25, z, 0, 1, r, mat, .6, .5, .4, 0.2, 1.5])
+        elif kind == 1:
+            recs.append([1, x, .25, z, x, .25 + rng.uniform(0, .6), z, 0.0, 1.0, r, mat, .3, .7, .4, 0.1, 1.5])
+        elif kind == 2:
+            recs.append([1, x, .25, z, x + rng.uniform(-.5, .5), .4, z + rng.uniform(-.5, .5), 0.25, 0.75, r, mat, .3, .3, .8, 0.0, 1.4])
+        else:
+            recs.append([1, x, .25, z, x, .25, z + .3, -1.0, 2.0, r, mat, .8, .3, .3, 0.4, 1.3])
+    recs.append([0, 0, 1, 0, 0, 1, 0, 0, 1, 1.0, 2, 0, 0, 0, 0, 1.5])
+    mixed = np.asarray(recs, dtype=np.float64)
+    base = tor.random_scene(0xFACADE)
+    out = [("random_scene", base, tor.camera()),
+           ("three time groups, hollow spheres, glass", tor.Scene.from_records(mixed), tor.camera(look_from=(10, 2.5, 4), aperture=0.05)),
+           ("random_scene from inside", base, tor.camera(look_from=(0.6, 0.7, 0.9), look_at=(4, 0.6, 0), vertical_field_of_view=60.0, aperture=0.02,
+                                                         focus_distance=3.0))]
+    shift = np.array([3e5, -2e5, 1e5])
+    moved = mixed.copy()
+    moved[:, 1:4] += shift
+    moved[:, 4:7] += shift
+    out.append(("everything 3e5 units from the origin", tor.Scene.from_records(moved),
+                tor.camera(look_from=tuple(float(x) for x in np.array([10, 2.5, 4]) + shift), look_at=tuple(float(x) for x in shift), aperture=0.05)))
+    return out
+
+
+def test_fma_screen_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
+    """Strict launches of the brute-force layouts run the wave-uniform object loop as a conservative FMA screen (11 / 12 / 14
+    float64 instructions per ray x object instead of the reference's 17 / 19 / 23 unfused operations); what it keeps is re-tested
+    with the reference's own operations (spheres.nim:29-48).  TOR_SCREEN=0 is rounds 1-2: the unfused discriminant for every
+    object.  Same canvas bit for bit, both stream layouts, four scenes; == the oracle; and the screen keeps a superset."""
+    import torch
+    objs, _ = ref_scene
+    for name, scene, cam in _screen_scenes(tor):
+        for seeding in (tor.SEED_SAMPLE, tor.SEED_PIXEL):
+            off, _ = _render_with_env(tor, scene, cam, 108, 192, 24, {"TOR_SCREEN": "0"}, seeding=seeding, accel=0)
+            on, _ = _render_with_env(tor, scene, cam, 108, 192, 24, {}, seeding=seeding, accel=0)
+            assert torch.equal(on, off), (name, seeding, int((on != off).sum()))
+            assert float(on.abs().sum()) > 0.0
+    h, w, spp = 90, 160, 32
+    for seeding in (0, 1):
+        want = oracle.render(h, w, spp, ref_camera, objs, seeding=seeding, math=1, arith=0).pixels
+        got, _ = _render_with_env(tor, tor.random_scene(0xFACADE), tor.camera(), h, w, spp, {}, seeding=seeding, accel=0)
+        _exact(got.cpu().numpy(), want)
+    # the candidate counts: same queries, the screen keeps at least what the sign filter of the unfused discriminant keeps
+    stats = {}
+    for key, env in (("off", {"TOR_SCREEN": "0"}), ("on", {})):
+        os.environ.update(env)
+        try:
+            ctx = tor.Context(0)
+        finally:
+            os.environ.pop("TOR_SCREEN", None)
+        ctx.upload(tor.random_scene(0xFACADE).list())
+        ctx.set_stats(True)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+        ctx.render_device(tor.camera(), h, w, spp, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE, accel=0), buf.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        stats[key] = ctx.last_stats()
+        ctx.close()
+    assert stats["on"].hit_queries == stats["off"].hit_queries and stats["on"].samples == stats["off"].samples
+    assert stats["off"].candidates <= stats["on"].candidates <= 1.6 * stats["off"].candidates, (stats["on"].candidates, stats["off"].candidates)

@@ -1,0 +1,97 @@
+"""The conservative FMA screen of the strict float64 object loop (csrc/tor_screen.hpp, integrate_kernel variants ARITH 2) may keep
+too much, never too little: everything it keeps is re-tested with the reference's own operations (spheres.nim:29-48), so a wrong
+"keep" costs time and a wrong "drop" would cost a pixel.  Host build of the kernel's own source against the reference's unfused
+test on random and adversarial ray / sphere pairs -- tangent rays to the last bit, origins on the surface (every scattered ray),
+huge offsets (random_scene's ground sphere: centre 1000 below, radius 1000), tiny and huge directions, moving centres with the
+time outside the object's interval.  CPU only."""
+import numpy as np
+import pytest
+
+from test_filter32 import _cases, _unit
+
+
+@pytest.mark.parametrize("scale,r_lo,r_hi,origin", [
+    (12.0, 0.2, 0.2, (0.0, 0.0, 0.0)),              # random_scene-like
+    (12.0, 0.05, 1.0, (3.0, 1.0, -2.0)),
+    (300.0, 0.01, 5.0, (1000.0, -2000.0, 500.0)),   # far from the world origin: cancellation in o - c
+    (2e4, 1.0, 100.0, (0.0, 0.0, 0.0)),
+    (0.01, 1e-4, 1e-3, (0.0, 0.0, 0.0)),            # tiny scene
+    (5.0, 900.0, 1100.0, (0.0, -1000.0, 0.0)),      # ground-sphere-like: radius ~ distance
+])
+def test_screen_never_drops_a_needed_object(tor, scale, r_lo, r_hi, origin):
+    rng = np.random.default_rng(int(scale * 1000) + 11)
+    origin = np.asarray(origin, dtype=np.float64)
+    n = 400_000
+    o, d, c0, dc, moving, f, r2 = _cases(rng, n, scale, r_lo, r_hi, origin)
+    keep, need = tor.selftest_screen(o, d, c0, dc, moving, f, r2)
+    missed = np.flatnonzero((need != 0) & (keep == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
+    assert np.count_nonzero(need) > n // 10
+
+
+def test_screen_on_the_decision_boundary(tor):
+    """Tangency to the last bit: directions perturbed by single ulps around the exact tangent, origins ON the sphere with
+    directions in the tangent plane, and the reference's own noise region |disc| ~ 1e-16 x |hb|^2."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    c0 = rng.uniform(-10, 10, size=(n, 3))
+    r = rng.choice([0.2, 1.0, 1000.0], size=n)
+    c0[r == 1000.0] = [0.0, -1000.0, 0.0]
+    nrm = _unit(rng, n)
+    o = c0 + nrm * r[:, None]                               # on the surface
+    tang = np.cross(nrm, _unit(rng, n))
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    lean = rng.choice([0.0, 1e-17, -1e-17, 1e-13, -1e-13, 1e-9, -1e-9, 1e-3, -1e-3], size=(n, 1))
+    d = (tang + nrm * lean) * rng.choice([1.0, 1e-4, 1e4, 1e-9], size=(n, 1))
+    # a second family: origin far away, ray through the exact tangent point, nudged by ulps
+    far = rng.random(n) < 0.5
+    o[far] = c0[far] + _unit(rng, int(far.sum())) * (r[far] * rng.uniform(1.5, 40.0, int(far.sum())))[:, None]
+    to_c = c0[far] - o[far]
+    dist = np.linalg.norm(to_c, axis=1)
+    w = to_c / dist[:, None]
+    perp = np.cross(w, _unit(rng, int(far.sum())))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    target = c0[far] + perp * r[far, None]
+    dd = target - o[far]
+    k = rng.integers(-3, 4, size=dd.shape)
+    d[far] = dd * (1.0 + k * 2.0 ** -52)
+    moving = np.zeros(n, dtype=np.int32)
+    keep, need = tor.selftest_screen(o, d, c0, np.zeros((n, 3)), moving, np.zeros(n), r * r)
+    missed = np.flatnonzero((need != 0) & (keep == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
+    assert 0 < np.count_nonzero(need) < n            # both sides of the boundary are present
+
+
+def test_screen_drops_the_obvious(tor):
+    """The margins are a few hundred ulps: on a realistic distribution the screen keeps (almost) exactly what the
+    reference's sign filter keeps -- the FMA form is not a blunter test."""
+    rng = np.random.default_rng(9)
+    n = 400_000
+    c0 = np.column_stack([rng.uniform(-11, 11, n), np.full(n, 0.2), rng.uniform(-11, 11, n)])
+    dc = np.column_stack([np.zeros(n), rng.uniform(0, 0.5, n), np.zeros(n)])
+    moving = np.ones(n, dtype=np.int32)
+    o = np.column_stack([rng.uniform(-11, 11, n), rng.uniform(0.0, 2.0, n), rng.uniform(-11, 11, n)])
+    d = _unit(rng, n)
+    keep, need = tor.selftest_screen(o, d, c0, dc, moving, rng.uniform(0, 1, n), np.full(n, 0.04))
+    assert np.count_nonzero((need != 0) & (keep == 0)) == 0
+    extra = np.count_nonzero((keep != 0) & (need == 0))
+    assert extra <= 4, extra        # only pairs within rounding distance of the boundary
+    assert 50 < np.count_nonzero(keep) < 0.01 * n        # a ray meets few of the small spheres
+
+
+def test_screen_degenerate_rays(tor):
+    """Zero, denormal-scale, huge and non-finite rays: the screen keeps, or the reference's own test rejects as well."""
+    n = 7
+    o = np.zeros((n, 3)); d = np.tile([0.0, 0.0, -1.0], (n, 1))
+    c0 = np.tile([0.0, 0.0, -5.0], (n, 1)); dc = np.zeros((n, 3)); moving = np.zeros(n, dtype=np.int32)
+    f = np.zeros(n); r2 = np.full(n, 0.25)
+    d[0] = 0.0
+    d[1] = [0, 0, -1e-160]
+    d[2] = [0, 0, -1e150]
+    o[3] = [np.inf, 0, 0]
+    o[4] = [np.nan, 0, 0]
+    moving[5] = 1; f[5] = 1e30; dc[5] = [0, 1, 0]
+    o[6] = [0, 0, 1e200]
+    keep, need = tor.selftest_screen(o, d, c0, dc, moving, f, r2)
+    assert np.all((need == 0) | (keep != 0)), (keep, need)
+    assert keep[1] and keep[2] and need[1] and need[2]

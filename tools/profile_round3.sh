@@ -10,9 +10,11 @@ python bench.py --workload c5 --accel blocks+f32 --steps 6 --warmup 2 > $O/r3_be
 python bench.py --gpus 2 --steps 2 --warmup 1 --verify --no-cpu-baseline > $O/r3_bench_2dev_strong.json 2> $O/r3_bench_2dev.err
 COMMON="--no-accel-leg --no-pmc --no-host-leg --no-stats"
 bash tools/profile_gpu.sh r3_c3 --spp 1000 $COMMON > $O/prof_r3_c3.log 2>&1
+TOR_SCREEN=0 bash tools/profile_gpu.sh r3_c3_unscreened --spp 1000 $COMMON > $O/prof_r3_c3_unscreened.log 2>&1
+bash tools/profile_gpu.sh r3_c2 --spp 100 $COMMON > $O/prof_r3_c2.log 2>&1
 bash tools/profile_gpu.sh r3_c3_pixel_default --spp 1000 --seeding pixel --accel blocks+f32 $COMMON > $O/prof_r3_c3_pixel_default.log 2>&1
 bash tools/profile_gpu.sh r3_c2_pixel_default --spp 100 --seeding pixel --accel blocks+f32 $COMMON > $O/prof_r3_c2_pixel_default.log 2>&1
-for t in r3_c3 r3_c3_pixel_default r3_c2_pixel_default; do
+for t in r3_c3 r3_c3_unscreened r3_c2 r3_c3_pixel_default r3_c2_pixel_default; do
   python tools/rocpd_summary.py $O/prof_$t $O/${t}_summary.txt > /dev/null
   rm -rf $O/prof_$t/*/
 done

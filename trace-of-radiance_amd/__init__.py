@@ -128,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "tor_last_kernel_ms", "tor_kernel_ms_mean", "tor_context_set_stats", "tor_last_stats", "tor_last_wave_log", "tor_camera_init",
     "tor_random_scene", "tor_canvas_to_rgb8", "tor_animation_create", "tor_animation_destroy",
     "tor_animation_object_count", "tor_animation_next", "tor_h264_stream_header", "tor_h264_frame_bytes",
-    "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_slab32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
+    "tor_encode_frame_device", "tor_render_frame_h264", "tor_mp4_mux_file", "tor_debug_accel_layout", "tor_selftest_filter32_host", "tor_selftest_screen_host", "tor_selftest_slab32_host", "tor_debug_filter32_scene", "tor_selftest_math_device", "tor_selftest_math_host",
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
     "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
@@ -234,6 +234,8 @@ def lib():
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32)]
     L.tor_selftest_filter32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
         [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2
+    L.tor_selftest_screen_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
+        [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_int32)] * 2
     L.tor_selftest_slab32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int32)] * 2
     L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
@@ -650,6 +652,22 @@ def selftest_filter32(o, d, c0, dc, moving, f, r2, origin):
                                             dc.ctypes.data_as(P), moving.ctypes.data_as(I), f.ctypes.data_as(P),
                                             r2.ctypes.data_as(P), origin.ctypes.data_as(P), keep.ctypes.data_as(I),
                                             need.ctypes.data_as(I)))
+    return keep, need
+
+
+def selftest_screen(o, d, c0, dc, moving, f, r2):
+    """(keep, need) int32 arrays: host build of the strict object loop's conservative FMA screen vs the reference's test."""
+    dp = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    o, d, c0, dc, f, r2 = dp(o), dp(d), dp(c0), dp(dc), dp(f), dp(r2)
+    moving = np.ascontiguousarray(moving, dtype=np.int32)
+    n = len(f)
+    keep = np.zeros(n, dtype=np.int32)
+    need = np.zeros(n, dtype=np.int32)
+    P = C.POINTER(C.c_double)
+    I = C.POINTER(C.c_int32)
+    _check(lib().tor_selftest_screen_host(n, o.ctypes.data_as(P), d.ctypes.data_as(P), c0.ctypes.data_as(P), dc.ctypes.data_as(P),
+                                          moving.ctypes.data_as(I), f.ctypes.data_as(P), r2.ctypes.data_as(P), keep.ctypes.data_as(I),
+                                          need.ctypes.data_as(I)))
     return keep, need
 
 

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "tor_context.hpp"
+#include "tor_screen.hpp"
 
 // ---- layout guards: the structs must match what Nim's C backend emits --------
 static_assert(sizeof(TorVec3) == 24, "Vec3 is 3 x float64 (vec3s.nim:12-14)");
@@ -314,6 +315,7 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = std::getenv("TOR_CHAIN_THETA")) ctx->chain_theta = (float)std::atof(c);
   if (const char* c = std::getenv("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
   if (const char* c = std::getenv("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
+  if (const char* c = std::getenv("TOR_SCREEN")) ctx->screen = std::atoi(c) != 0;
   if (const char* c = std::getenv("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
   if (const char* c = std::getenv("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
   if (const char* c = std::getenv("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
@@ -704,6 +706,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   if (waves > resident_waves) waves = resident_waves;
   int blocks = (int)((waves + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
   if (blocks < 1) blocks = 1;
+  p.screen = ctx->screen ? 1 : 0;
   p.n_boxes = use_accel ? (int)((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) : 0;
   p.mig = nullptr;
   const bool migrate = mig_candidate && use_accel && n_tiles > 1 && tor::integrate_variant_serves_chains(p, o.seeding) && resident_waves >= 8;
@@ -1039,6 +1042,11 @@ int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]) {
   auto us = [&](unsigned long long t) { return (t == 0 || t == ~0ull || t < t0) ? 0ull : (t - t0) / 100ull; };
   out[8] = us(h[tor::kMigTCounterDry]); out[9] = us(h[tor::kMigTLaneEnd]); out[10] = us(h[tor::kMigTHotDone]); out[11] = us(h[tor::kMigTTailDone]);
   out[12] = h[tor::kMigItsHot]; out[13] = h[tor::kMigItsTail]; out[14] = h[tor::kMigConverted]; out[15] = h[tor::kMigPushNow];
+#ifdef TOR_SERVE_PROF
+  // profiling build (make SERVE_PROF=1, tools/server_phases.py): shader-clock ticks per phase of the served bounces
+  std::fprintf(stderr, "serve_prof query %llu lambertian %llu metal %llu dielectric %llu miss %llu setup %llu n_lambertian %llu n_metal %llu n_dielectric %llu "
+               "n_miss %llu rounds %llu candidates %llu total %llu samples %llu\n", h[81], h[82], h[83], h[84], h[85], h[86], h[87], h[88], h[89], h[90], h[91], h[92], h[93], h[94]);
+#endif
   return TOR_OK;
 }
 
@@ -1215,6 +1223,47 @@ int tor_selftest_filter32_host(int64_t n, const double* o, const double* d, cons
       const double root = std::sqrt(disc);
       const double s0 = (-hb - root) / a, s1 = (-hb + root) / a;
       if ((0.001 < s0 && s0 < INFINITY) || (0.001 < s1 && s1 < INFINITY)) nd |= 2;
+    }
+    need[i] = nd;
+  }
+  return TOR_OK;
+}
+
+// The conservative FMA screen of the strict object loop (tor_screen.hpp) on the HOST: ray i against sphere i, with the
+// margins the kernel would use for a segment that holds only this object (the smallest margins the host ever hands out).
+// keep[i] = the screen keeps the object; need[i] as in tor_selftest_filter32_host.
+int tor_selftest_screen_host(int64_t n, const double* o, const double* d, const double* c0, const double* dc,
+                             const int32_t* moving, const double* f, const double* r2, int32_t* keep, int32_t* need) {
+  if (n < 0 || !o || !d || !c0 || !dc || !moving || !f || !r2 || !keep || !need)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_screen_host: bad argument");
+  auto up = [](double x) { return x * (1.0 + 0x1p-40); };
+  for (int64_t i = 0; i < n; ++i) {
+    const double* oo = o + 3 * i; const double* dd = d + 3 * i; const double* cc0 = c0 + 3 * i; const double* dcc = dc + 3 * i;
+    const bool mv = moving[i] != 0;
+    const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+    // tor_scene.cpp build_layout: segs[6], segs[7]
+    const double reach = up(std::sqrt(cc0[0] * cc0[0] + cc0[1] * cc0[1] + cc0[2] * cc0[2]) + std::sqrt(std::fabs(r2[i])));
+    const double travel = mv ? up(std::sqrt(dcc[0] * dcc[0] + dcc[1] * dcc[1] + dcc[2] * dcc[2])) : 0.0;
+    const double s1 = std::fabs(oo[0]) + std::fabs(oo[1]) + std::fabs(oo[2]);
+    const double d1 = std::fabs(dd[0]) + std::fabs(dd[1]) + std::fabs(dd[2]);
+    double negmu, am;
+    tor::screen_margins(s1 + reach + travel * std::fabs(mv ? f[i] : 0.0), d1, a, negmu, am);
+    const double nf = -f[i];
+    const double sx = mv ? tor::fma_(nf, dcc[0], oo[0] - cc0[0]) : oo[0] - cc0[0];
+    const double sy = mv ? tor::fma_(nf, dcc[1], oo[1] - cc0[1]) : oo[1] - cc0[1];
+    const double sz = mv ? tor::fma_(nf, dcc[2], oo[2] - cc0[2]) : oo[2] - cc0[2];
+    keep[i] = tor::screen_filter(sx, sy, sz, dd[0], dd[1], dd[2], a, negmu, am, r2[i]) < 0 ? 1 : 0;
+    double c[3] = {cc0[0], cc0[1], cc0[2]};
+    if (mv) for (int k = 0; k < 3; ++k) c[k] = cc0[k] + dcc[k] * f[i];  // moving_spheres.nim:43
+    const double ocx = oo[0] - c[0], ocy = oo[1] - c[1], ocz = oo[2] - c[2];
+    const double hb = ocx * dd[0] + ocy * dd[1] + ocz * dd[2];
+    const double cq = (ocx * ocx + ocy * ocy + ocz * ocz) - r2[i];
+    const double disc = hb * hb - a * cq;
+    int32_t nd = (disc > 0.0 && (hb < 0.0 || cq < 0.0)) ? 1 : 0;
+    if (disc > 0.0) {
+      const double root = std::sqrt(disc);
+      const double s0 = (-hb - root) / a, s1r = (-hb + root) / a;
+      if ((0.001 < s0 && s0 < INFINITY) || (0.001 < s1r && s1r < INFINITY)) nd |= 2;
     }
     need[i] = nd;
   }

@@ -133,6 +133,7 @@ struct TorContext {
   std::vector<double> probe_bnd_host[kRing];  // block bounds of the cost probe when it runs with other accel bits than the frame (host staging of an
   std::vector<float> probe_bnd32_host[kRing];  // asynchronous copy, per ring slot like bnd_host)
   bool probe_accel = true;  // TOR_PROBE_ACCEL=0: the probe walks the same layout as the frame's kernel
+  bool screen = true;       // TOR_SCREEN=0: strict brute-force launches evaluate the reference's unfused discriminant for every object (no FMA screen)
   hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
   int64_t launches = 0;  // timed integrator launches so far
   bool timing_valid = false;

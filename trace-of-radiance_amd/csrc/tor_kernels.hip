@@ -56,6 +56,7 @@
 
 #include "tor_device.hpp"
 #include "tor_kernels.hpp"
+#include "tor_screen.hpp"
 
 namespace tor {
 
@@ -93,7 +94,7 @@ __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, doub
                                            double r2) {
   double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
   double hb, cc, disc;
-  if (ARITH == 0) {
+  if (ARITH != 1) {
     hb = ocx * dx + ocy * dy + ocz * dz;          // spheres.nim:31
     cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;  // spheres.nim:32
     disc = hb * hb - a * cc;                      // spheres.nim:33
@@ -108,6 +109,8 @@ __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, doub
   return (hi32(hb) | hi32(cc)) & ~hi32(disc);
 #endif
 }
+
+// (ARITH 2, the conservative FMA screen of the strict object loop: tor_screen.hpp)
 
 // candidate-queue entries per lane (LDS, u32): (block << 8) | 8-bit mask.  Brute-force scenes queue one entry per
 // 8 objects with a candidate; with TOR_ACCEL_BLOCKS the entries are box masks (8 blocks each) and a lane rarely
@@ -532,17 +535,25 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     // super boxes (two-level culling layouts, > 96 blocks): the cooperative variants carry that code only as BLOCKS = 2
     // -- compiled into the single-level variants it cost them ~1 % (registers) -- the others always
     constexpr bool kSuper = BLOCKS == 2 || (BLOCKS == 1 && F32 == 0);
+    // ARITH 2: the reference's arithmetic (as ARITH 0) behind a conservative FMA screen in the wave-uniform object loop
+    constexpr bool kScreen = ARITH == 2;
     {
       // ================= (B) closest hit over all objects ==============================
       // hittables_lists.nim:48-55 with t_min = 0.001, t_max = Inf (render.nim:28)
       // (computed by every lane: a lane without a live path works on stale values that nobody reads)
       const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
       const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
-      const double a = (ARITH == 0) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
+      const double a = (ARITH != 1) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
       double best_t = __builtin_inf();
       int best_idx = -1;
       int best_orig = 0x7fffffff;
       double best_f = 0.0;
+      // ARITH 2 (conservative FMA screen, screen_filter above): the ray's share of the margins
+      double scr_s1 = 0.0, scr_d1 = 0.0, scr_negmu = 0.0, scr_am = 0.0;
+      if (kScreen) {
+        scr_s1 = __builtin_fabs(ox) + __builtin_fabs(oy) + __builtin_fabs(oz);
+        scr_d1 = __builtin_fabs(dx) + __builtin_fabs(dy) + __builtin_fabs(dz);
+      }
 
       // TOR_ACCEL_F32: the ray in float32, relative to the scene origin (used by segment kinds 5-7 only)
       RayF32 r32{};
@@ -590,6 +601,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             // requested one object ahead of its use (s_load latency hides under ~17 VALU ops)
             cdptr rec = stat + 4 * (long)(seg_begin + i);
             double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+            if (kScreen) screen_margins(scr_s1 + segs[seg * 8 + 6], scr_d1, a, scr_negmu, scr_am);
             for (; i < seg_count; i += kBlock) {
               unsigned m = 0;
 #pragma unroll
@@ -597,7 +609,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 const double c0 = n0, c1 = n1, c2 = n2, c3 = n3;
                 n0 = rec[4 * (j + 1) + 0]; n1 = rec[4 * (j + 1) + 1];   // next object (the arrays carry one
                 n2 = rec[4 * (j + 1) + 2]; n3 = rec[4 * (j + 1) + 3];   // record of slack past the last block)
-                m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0, c1, c2, c3));
+                if (kScreen) m = push_bit(m, screen_filter(ox - c0, oy - c1, oz - c2, dx, dy, dz, a, scr_negmu, scr_am, c3));
+                else m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0, c1, c2, c3));
               }
               rec += 4 * kBlock;
               q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
@@ -733,6 +746,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             // moving_spheres.nim:39-44: f = (time - time0) / (time1 - time0)
             const double t0 = segs[seg * 8 + 4], dt = segs[seg * 8 + 5];
             const double f = (time - t0) / dt;
+            if (kScreen) screen_margins(scr_s1 + segs[seg * 8 + 6] + segs[seg * 8 + 7] * __builtin_fabs(f), scr_d1, a, scr_negmu, scr_am);
+            const double neg_f = -f;
             if (seg_kind == 1) {
               // every sphere of the segment moves along y only (center1.x == center0.x and
               // center1.z == center0.z): c0 + f*0 == c0 exactly, so x and z need no arithmetic
@@ -745,8 +760,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   const double c0x = n0, c0y = n1, c0z = n2, r2 = n3, dcy = n4;
                   n0 = rec[6 * (j + 1) + 0]; n1 = rec[6 * (j + 1) + 1]; n2 = rec[6 * (j + 1) + 2];
                   n3 = rec[6 * (j + 1) + 3]; n4 = rec[6 * (j + 1) + 4];
-                  const double cy = (ARITH == 0) ? c0y + dcy * f : fma_(dcy, f, c0y);
-                  m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0x, cy, c0z, r2));
+                  if (kScreen) {
+                    // (centre folded into oc: o - (c0 + dc f) as fma(-f, dc, o - c0), one scalar operand per instruction)
+                    m = push_bit(m, screen_filter(ox - c0x, fma_(neg_f, dcy, oy - c0y), oz - c0z, dx, dy, dz, a, scr_negmu, scr_am, r2));
+                  } else {
+                    const double cy = (ARITH != 1) ? c0y + dcy * f : fma_(dcy, f, c0y);
+                    m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0x, cy, c0z, r2));
+                  }
                 }
                 rec += 6 * kBlock;
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
@@ -761,13 +781,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   const int k = seg_begin + i + j;
                   const double c0x = mov[8 * k + 0], c0y = mov[8 * k + 1], c0z = mov[8 * k + 2];
                   const double dcx = mov[8 * k + 4], dcy = mov[8 * k + 5], dcz = mov[8 * k + 6];
-                  double cx, cy, cz;
-                  if (ARITH == 0) {
-                    cx = c0x + dcx * f; cy = c0y + dcy * f; cz = c0z + dcz * f;
+                  if (kScreen) {
+                    m = push_bit(m, screen_filter(fma_(neg_f, dcx, ox - c0x), fma_(neg_f, dcy, oy - c0y), fma_(neg_f, dcz, oz - c0z), dx, dy, dz, a,
+                                                  scr_negmu, scr_am, mov[8 * k + 3]));
                   } else {
-                    cx = fma_(dcx, f, c0x); cy = fma_(dcy, f, c0y); cz = fma_(dcz, f, c0z);
+                    double cx, cy, cz;
+                    if (ARITH != 1) {
+                      cx = c0x + dcx * f; cy = c0y + dcy * f; cz = c0z + dcz * f;
+                    } else {
+                      cx = fma_(dcx, f, c0x); cy = fma_(dcy, f, c0y); cz = fma_(dcz, f, c0z);
+                    }
+                    m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, mov[8 * k + 3]));
                   }
-                  m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, mov[8 * k + 3]));
                 }
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
@@ -815,12 +840,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               if (flags & 1) {
                 // the owner already divided for the spatial movers' time group: same operands, same quotient
                 const double f = (c[7] == p.sp_t0 && c[8] == p.sp_dt) ? sfsp : (stime - c[7]) / c[8];
-                if (ARITH == 0) { cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f; }
+                if (ARITH != 1) { cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f; }
                 else { cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz); }
               }
               const double ocx = sox - cx, ocy = soy - cy, ocz = soz - cz;
               double hb, cc, disc;
-              if (ARITH == 0) {
+              if (ARITH != 1) {
                 hb = ocx * sdx + ocy * sdy + ocz * sdz;
                 cc = (ocx * ocx + ocy * ocy + ocz * ocz) - c[15];
                 disc = hb * hb - sa * cc;
@@ -1123,7 +1148,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         auto exact_hit = [&](double cx, double cy, double cz, double r2, unsigned idx, double f) {
           const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
           double hb, cc, disc;
-          if (ARITH == 0) {
+          if (ARITH != 1) {
             hb = ocx * dx + ocy * dy + ocz * dz;
             cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
             disc = hb * hb - a * cc;
@@ -1164,7 +1189,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               f_gid = gid;
             }
             f = f_val;
-            if (ARITH == 0) {
+            if (ARITH != 1) {
               cx = cx + hrec[4] * f; cy = cy + hrec[5] * f; cz = cz + hrec[6] * f;
             } else {
               cx = fma_(hrec[4], f, cx); cy = fma_(hrec[5], f, cy); cz = fma_(hrec[6], f, cz);
@@ -1178,7 +1203,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           const int flags = (int)__double_as_longlong(c[13]);
           if (flags & 1) {
             f = (time - c[7]) / c[8];
-            if (ARITH == 0) {
+            if (ARITH != 1) {
               cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f;
             } else {
               cx = fma_(c[3], f, cx); cy = fma_(c[4], f, cy); cz = fma_(c[5], f, cz);
@@ -1301,7 +1326,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         const int flags = (int)__double_as_longlong(c[13]);
         V3 center = v3(c[0], c[1], c[2]);
         if (flags & 1) {
-          if (ARITH == 0) center = center + v3(c[3], c[4], c[5]) * best_f;
+          if (ARITH != 1) center = center + v3(c[3], c[4], c[5]) * best_f;
           else center = v3(fma_(c[3], best_f, c[0]), fma_(c[4], best_f, c[1]), fma_(c[5], best_f, c[2]));
         }
         const V3 hp = o + d * best_t;                       // rays.nim:24-25
@@ -1916,6 +1941,11 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
     const int s_begin = (int)((rec[0] >> 32) & 0x7fffffffull);
     const bool was_hot = (rec[0] >> 63) != 0;
     unsigned chain_its = 0;
+#ifdef TOR_SERVE_PROF
+    // (profiling build only, tools/server_phases.py: shader-clock ticks per phase of a served bounce)
+    unsigned long long pf_query = 0, pf_shade[3] = {0, 0, 0}, pf_miss = 0, pf_setup = 0, pf_n[3] = {0, 0, 0}, pf_nmiss = 0, pf_rounds = 0, pf_cand = 0;
+    const unsigned long long pf_begin = __builtin_readcyclecounter();
+#endif
     Rng rng{rec[1], rec[2], rec[3], rec[4]};
     V3 acc = v3(bits_to_double(rec[5]), bits_to_double(rec[6]), bits_to_double(rec[7]));
     const unsigned lrow = pl / (unsigned)p.ncols;
@@ -1928,6 +1958,9 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
     if (was_hot || !(p.mig_flags & 4u)) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(1);
     for (int s = s_begin; s < p.spp; ++s) {
+#ifdef TOR_SERVE_PROF
+      const unsigned long long pf_s0 = __builtin_readcyclecounter();
+#endif
       // render.nim:64-66
       const double u = ((double)col + uniform01(rng)) / w_div;
       const double v = ((double)row + uniform01(rng)) / h_div;
@@ -1936,12 +1969,18 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
       V3 o = r0.origin, d = r0.direction, att = v3(1.0, 1.0, 1.0);
       double time = r0.time;
       V3 radiance = v3(0.0, 0.0, 0.0);  // absorbed / loop exhausted -> black (render.nim:38,47)
+#ifdef TOR_SERVE_PROF
+      pf_setup += __builtin_readcyclecounter() - pf_s0;
+#endif
       for (int depth = 0; depth < p.max_depth; ++depth) {
         // ---- closest hit (hittables_lists.nim:48-55), boxes and candidates split across the lanes ----
         chain_its += 1;
+#ifdef TOR_SERVE_PROF
+        const unsigned long long pf_q0 = __builtin_readcyclecounter();
+#endif
         const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
         const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
-        const double a = (ARITH == 0) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
+        const double a = (ARITH != 1) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
         const RayF32 r32 = make_ray_f32(ox, oy, oz, dx, dy, dz, a_strict, p.org[0], p.org[1], p.org[2]);
         const BoxRay32 b32 = make_box_ray32(r32, p.sp_bmax);
         const unsigned wild = r32.wild & 1u;  // a ray outside the float32 test's guarded ranges enters every box
@@ -1980,12 +2019,12 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
             double f = f_sp;  // (the spatial movers share one time group: same operands as the division, same quotient)
             if (moving && !(k7 == p.sp_t0 && k8 == p.sp_dt)) f = (time - k7) / k8;
             double mx, my, mz;  // centre of a mover (moving_spheres.nim:43); a static sphere keeps c0 untouched
-            if (ARITH == 0) { mx = k0 + k3 * f; my = k1 + k4 * f; mz = k2 + k5 * f; }
+            if (ARITH != 1) { mx = k0 + k3 * f; my = k1 + k4 * f; mz = k2 + k5 * f; }
             else { mx = fma_(k3, f, k0); my = fma_(k4, f, k1); mz = fma_(k5, f, k2); }
             const double cx = moving ? mx : k0, cy = moving ? my : k1, cz = moving ? mz : k2;
             const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
             double hb, cc, disc;
-            if (ARITH == 0) {
+            if (ARITH != 1) {
               hb = ocx * dx + ocy * dy + ocz * dz;             // spheres.nim:31
               cc = (ocx * ocx + ocy * ocy + ocz * ocz) - k15;  // spheres.nim:32
               disc = hb * hb - a * cc;                         // spheres.nim:33
@@ -2015,8 +2054,18 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
           }
         }
         const double t_min = wave_min_f64(best_t);
+#ifdef TOR_SERVE_PROF
+        const unsigned long long pf_q1 = __builtin_readcyclecounter();
+        pf_query += pf_q1 - pf_q0;
+        pf_rounds += (n_cand + 63u) / 64u;
+        pf_cand += n_cand;
+#endif
         if (!(t_min < __builtin_inf())) {
           radiance = sky(d, att);  // render.nim:41-45
+#ifdef TOR_SERVE_PROF
+          pf_miss += __builtin_readcyclecounter() - pf_q1;
+          pf_nmiss += 1;
+#endif
           break;
         }
         unsigned long long win = ballot64(best_t == t_min);
@@ -2072,6 +2121,14 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
           time = 0.0;
           // (attenuation (1, 1, 1), materials.nim:63: x * 1.0 == x, nothing to do)
         }
+#ifdef TOR_SERVE_PROF
+        {
+          // (o.x is the last value the shading produces: the read waits for it)
+          const unsigned long long pf_now = __builtin_readcyclecounter() + (double_to_bits(d.x + d.y + d.z) == 1ull ? 1ull : 0ull);
+          pf_shade[mat] += pf_now - pf_q1;
+          pf_n[mat] += 1;
+        }
+#endif
         if (absorbed) break;  // render.nim:38
       }
       acc = acc + radiance;  // render.nim:67
@@ -2081,6 +2138,13 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
     out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
     if (lane == 0) {
       atomicAdd(p.mig + kMigServed, 1ull);
+#ifdef TOR_SERVE_PROF
+      atomicAdd(p.mig + 81, pf_query); atomicAdd(p.mig + 82, pf_shade[0]); atomicAdd(p.mig + 83, pf_shade[1]); atomicAdd(p.mig + 84, pf_shade[2]);
+      atomicAdd(p.mig + 85, pf_miss); atomicAdd(p.mig + 86, pf_setup); atomicAdd(p.mig + 87, pf_n[0]); atomicAdd(p.mig + 88, pf_n[1]);
+      atomicAdd(p.mig + 89, pf_n[2]); atomicAdd(p.mig + 90, pf_nmiss); atomicAdd(p.mig + 91, pf_rounds); atomicAdd(p.mig + 92, pf_cand);
+      atomicAdd(p.mig + 93, (unsigned long long)__builtin_readcyclecounter() - pf_begin);
+      atomicAdd(p.mig + 94, (unsigned long long)(p.spp - s_begin));
+#endif
       atomicAdd(p.mig + (was_hot ? kMigItsHot : kMigItsTail), (unsigned long long)chain_its);
       atomicMax(p.mig + (was_hot ? kMigTHotDone : kMigTTailDone), (unsigned long long)wall_clock64());
     }
@@ -2366,6 +2430,8 @@ static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32, int
   TOR_V4(0, 0, 2) TOR_V4(0, 1, 2) TOR_V4(1, 0, 2) TOR_V4(1, 1, 2)
   TOR_V4(0, 0, 3) TOR_V4(0, 1, 3) TOR_V4(1, 0, 3) TOR_V4(1, 1, 3)
   TOR_V4(2, 0, 3)   // cost probe of the SEED_PIXEL tile schedule
+  // arith 2: the reference's arithmetic behind the conservative FMA screen (brute-force layouts only)
+  TOR_V(0, 2, 2, 0, 0) TOR_V(0, 2, 3, 0, 0) TOR_V(1, 2, 2, 0, 0) TOR_V(1, 2, 3, 0, 0) TOR_V(2, 2, 3, 0, 0)
 #undef TOR_V4
 #undef TOR_V
   return nullptr;
@@ -2383,8 +2449,14 @@ static size_t dynamic_lds(const KParams& p) {
          (size_t)p.bnd32_lds_floats * 4;
 }
 
+// arith as the caller asked (0 strict, 1 fused) -> the kernel variant: strict launches of the brute-force layouts run behind
+// the conservative FMA screen (variant 2: the same canvas bit for bit) unless the context turned it off (KParams::screen)
+static int arith_variant(const KParams& p, int arith) {
+  return (arith == 0 && p.screen != 0 && wants_f32(p) == 0 && wants_blocks(p) == 0) ? 2 : arith;
+}
+
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
-  IntegrateFn fn = integrate_variant(2, 0, 3, wants_f32(p), wants_blocks(p));
+  IntegrateFn fn = integrate_variant(2, arith_variant(p, 0), 3, wants_f32(p), wants_blocks(p));
   if (!fn) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p), stream, p);
   return hipGetLastError();
@@ -2413,14 +2485,14 @@ bool integrate_variant_serves_chains(const KParams& p, int seeding) {
 
 hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_per_simd, int blocks,
                             hipStream_t stream) {
-  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
+  IntegrateFn fn = integrate_variant(seeding, arith_variant(p, arith), clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
   if (!fn) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p), stream, p);
   return hipGetLastError();
 }
 
 int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_per_simd) {
-  IntegrateFn fn = integrate_variant(seeding, arith, clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
+  IntegrateFn fn = integrate_variant(seeding, arith_variant(p, arith), clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
   int n = 0;
   if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, dynamic_lds(p)) != hipSuccess || n < 1) n = 1;
   return n;

@@ -89,6 +89,7 @@ struct KParams {
   int mig_tail_rest;            // ... with more live lanes than that: only chains with at least this many bounce iterations to go, and only to idle servers
   unsigned mig_patience;        // 100 MHz ticks a dedicated server waits without a chain before it turns into a lane wave (0: never)
   unsigned mig_flags;           // bit 0: acquire (not relaxed) polling; bit 1: adaptive push threshold; bits 8-15: longest back-off of a waiting server in naps of ~3.4 us; bits 16-31: at most this many waiting servers (0 = no limit)
+  int screen;                   // strict launches of brute-force layouts: 1 = conservative FMA screen in the object loop (kernel variant ARITH 2; same canvas), 0 = the reference's unfused discriminant for every object
   int n_boxes;                  // block boxes of a single-level culling layout (padded to kPad), the servers' first trip
 };
 

@@ -191,9 +191,18 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   for (size_t k = 0; k < n_movy_p; ++k) out.movy[6 * k + 3] = -1.0;
   for (size_t k = 0; k < out.n_sorted; ++k) out.cold[16 * k + 15] = -1.0;
 
+  // segs[6], segs[7] of the float64 segments (kinds 0-2): what the conservative FMA screen of the strict object loop needs to
+  // know about the segment's members (tor_kernels.hip: screen_filter) -- an upper bound of |c0| + |r| and of |c1 - c0|.  A
+  // non-finite bound turns into infinite margins there: everything is kept and the exact test decides.
+  auto up = [](double x) { return x * (1.0 + 0x1p-40); };
   size_t sorted = 0;
   if (!statics.empty()) {
-    out.segs.insert(out.segs.end(), {0.0, 0.0, (double)n_stat_p, 0.0, 0.0, 0.0, 0.0, 0.0});
+    double reach = 0.0;
+    for (size_t k = 0; k < statics.size(); ++k) {
+      const TorSphere& s = objs[statics[k]].u.sphere;
+      reach = std::fmax(reach, norm3(s.center.x, s.center.y, s.center.z) + std::fabs(s.radius));
+    }
+    out.segs.insert(out.segs.end(), {0.0, 0.0, (double)n_stat_p, 0.0, 0.0, 0.0, up(reach), 0.0});
     for (size_t k = 0; k < statics.size(); ++k) {
       const TorSphere& s = objs[statics[k]].u.sphere;
       out.stat[4 * k + 0] = s.center.x; out.stat[4 * k + 1] = s.center.y; out.stat[4 * k + 2] = s.center.z;
@@ -209,8 +218,14 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     const TorMovingSphere& first = objs[g.ids[0]].u.moving_sphere;
     const double t0 = first.time0, dt = first.time1 - first.time0;
     const bool y = yonly[gi] != 0;
+    double reach = 0.0, travel = 0.0;
+    for (int64_t idx : g.ids) {
+      const TorMovingSphere& s = objs[idx].u.moving_sphere;
+      reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
+      travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
+    }
     out.segs.insert(out.segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)cnt_p,
-                                     (double)(sorted / kPad), t0, dt, 0.0, 0.0});
+                                     (double)(sorted / kPad), t0, dt, up(reach), up(travel)});
     for (size_t k = 0; k < g.ids.size(); ++k) {
       const TorMovingSphere& s = objs[g.ids[k]].u.moving_sphere;
       const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
