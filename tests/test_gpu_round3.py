@@ -371,7 +371,7 @@ def test_fma_screen_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
             assert float(on.abs().sum()) > 0.0
     h, w, spp = 90, 160, 32
     for seeding in (0, 1):
-        want = oracle.render(h, w, spp, ref_camera, objs, seeding=seeding, math=1, arith=0).pixels
+        want = oracle.render(h, w, spp, ref_camera, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels   # (accum 1: 2^-36 quanta, as SEED_SAMPLE sums)
         got, _ = _render_with_env(tor, tor.random_scene(0xFACADE), tor.camera(), h, w, spp, {}, seeding=seeding, accel=0)
         _exact(got.cpu().numpy(), want)
     # the candidate counts: same queries, the screen keeps at least what the sign filter of the unfused discriminant keeps

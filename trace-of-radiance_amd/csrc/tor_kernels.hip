@@ -1446,7 +1446,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               unsigned long long* r = p.mig_rec + at * 8;
               r[0] = (unsigned long long)(unsigned)pix | ((unsigned long long)(unsigned)s << 32) | (hot ? 1ull << 63 : 0ull);
               r[1] = rng.s0; r[2] = rng.s1; r[3] = rng.s2; r[4] = rng.s3;
-              r[5] = double_to_bits(acc.x); r[6] = double_to_bits(acc.y); r[7] = double_to_bits(acc.z);
+              // (the running sum comes back from LDS, where the sample boundary above left it: kept in registers across this
+              // block it was spilled -- one 16-byte scratch store per finished sample, 24 GB of HBM writes per configs[2] frame)
+              if (kAccInLds) { r[5] = double_to_bits(pix_acc[0]); r[6] = double_to_bits(pix_acc[64]); r[7] = double_to_bits(pix_acc[128]); }
+              else { r[5] = double_to_bits(acc.x); r[6] = double_to_bits(acc.y); r[7] = double_to_bits(acc.z); }
               __hip_atomic_store(p.mig_flag + at, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
               have_item = false;  // the lane is free again
               atomicAdd(mq + (hot ? kMigHotPushes : kMigTailPushes), 1ull);
