@@ -1,11 +1,13 @@
-"""Differential fuzz of the exact accelerations on the GPU: random scenes and cameras, every accel mode against the
-float64 brute-force canvas, bit for bit.  Usage: python tools/fuzz_accel.py [seconds] [seed]"""
+"""Differential fuzz of the exact accelerations on the GPU: random scenes and cameras, every accel mode -- and the brute force
+WITHOUT its conservative FMA screen (TOR_SCREEN=0) -- against the float64 brute-force canvas, bit for bit.
+Usage: python tools/fuzz_accel.py [seconds] [seed]"""
 import importlib
 import os
 import sys
 import time
 
 import numpy as np
+import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tor = importlib.import_module("trace-of-radiance_amd")
@@ -49,6 +51,9 @@ def random_scene(rng):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    os.environ["TOR_SCREEN"] = "0"
+    unscreened = tor.Context(0)      # (the knob is read when a context is made; tor.render() below uses the default context)
+    os.environ.pop("TOR_SCREEN", None)
     t0 = time.time()
     n_scenes = n_renders = bad = 0
     while time.time() - t0 < budget:
@@ -64,6 +69,17 @@ def main():
                 tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, accel=accel, pixel_kernel=1))
                 canv.append(cv.pixels.copy())
                 n_renders += 1
+            # the same brute force without the FMA screen: every object through the reference's unfused discriminant
+            unscreened.upload(scene.list())
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+            unscreened.render_device(cam, h, w, spp, 2.2, depth, tor.make_options(seeding=seeding, accel=0, pixel_kernel=1), buf.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            plain = buf.cpu().numpy()
+            n_renders += 1
+            if not np.array_equal(canv[0], plain, equal_nan=True):
+                bad += 1
+                print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} TOR_SCREEN=0: {int((canv[0] != plain).sum())} values differ", flush=True)
             if seeding == 0:  # the wave-per-pixel kernel (TorOptions.pixel_kernel = 2) against the lane kernel's brute force
                 cv = tor.new_canvas(h, w, spp, 2.2)
                 tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=0, accel=0, pixel_kernel=2))
