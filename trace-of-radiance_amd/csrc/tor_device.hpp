@@ -74,25 +74,32 @@ TOR_HD uint64_t next(Rng& g) {
   g.s3 = (g.s3 << 45) | (g.s3 >> 19);
   return res;
 }
-// rng.nim:129-133
-TOR_HD double uniform01(Rng& g) {
-  uint64_t m = next(g) >> 12;
-  return bits_to_double(m | 0x3ff0000000000000ULL) - 1.0;
-}
+// The samplers below take the generator as a template parameter G: `Rng` (a lane's or the host's own xoshiro256+ state), or the
+// chain servers' block generator (tor_kernels.hip: SrvRng -- the same stream, 64 outputs at a time, one lane per output);
+// all they need is `uint64_t next(G&)`.
+// rng.nim:129-133, from one 64-bit output
+TOR_HD double uniform01_of(uint64_t out) { return bits_to_double((out >> 12) | 0x3ff0000000000000ULL) - 1.0; }
+template <class G>
+TOR_HD double uniform01(G& g) { return uniform01_of(next(g)); }
 // rng.nim:135-143
-TOR_HD double uniform_max(Rng& g, double max_excl) { return uniform01(g) * max_excl; }
+TOR_HD double uniform_max_of(uint64_t out, double max_excl) { return uniform01_of(out) * max_excl; }
+template <class G>
+TOR_HD double uniform_max(G& g, double max_excl) { return uniform_max_of(next(g), max_excl); }
 // rng.nim:116-127 (Nim's max(x, y) is `if y <= x: x else: y`)
-TOR_HD double uniform_range(Rng& g, double lo, double hi) {
-  double d = uniform01(g);
+TOR_HD double uniform_range_of(uint64_t out, double lo, double hi) {
+  double d = uniform01_of(out);
   double v = d * (hi - lo) + lo;
   return (v <= lo) ? lo : v;
 }
+template <class G>
+TOR_HD double uniform_range(G& g, double lo, double hi) { return uniform_range_of(next(g), lo, hi); }
 
 // ---------------------------------------------------------------------------------------
 // Samplers -- sampling.nim
 // ---------------------------------------------------------------------------------------
 // sampling.nim:64-68
-TOR_HD V3 random_in_unit_disk(Rng& g) {
+template <class G>
+TOR_HD V3 random_in_unit_disk(G& g) {
   for (;;) {
     double x = uniform_range(g, -1.0, 1.0);
     double y = uniform_range(g, -1.0, 1.0);
@@ -100,7 +107,8 @@ TOR_HD V3 random_in_unit_disk(Rng& g) {
   }
 }
 // sampling.nim:45-49
-TOR_HD V3 random_in_unit_sphere(Rng& g) {
+template <class G>
+TOR_HD V3 random_in_unit_sphere(G& g) {
   for (;;) {
     double x = uniform_range(g, -1.0, 1.0);
     double y = uniform_range(g, -1.0, 1.0);
@@ -109,7 +117,15 @@ TOR_HD V3 random_in_unit_sphere(Rng& g) {
     if (len2(p) < 1.0) return p;
   }
 }
-// sampling.nim:51-55
+// sampling.nim:51-55, from the two outputs it draws
+TOR_HD V3 random_unit_vector_of(uint64_t out_a, uint64_t out_z) {
+  double a = uniform_max_of(out_a, 2.0 * 3.141592653589793);
+  double z = uniform_range_of(out_z, -1.0, 1.0);
+  double r = __builtin_sqrt(1.0 - z * z);
+  double s, c;
+  sincos_2pi(a, s, c);
+  return V3{r * c, r * s, z};
+}
 TOR_HD V3 random_unit_vector(Rng& g) {
   double a = uniform_max(g, 2.0 * 3.141592653589793);
   double z = uniform_range(g, -1.0, 1.0);
@@ -133,7 +149,8 @@ struct Camera {  // cameras.nim:15-22, same field order as TorCamera
 };
 
 // cameras.nim:47-57
-TOR_HD Ray camera_ray(const Camera& c, double s, double t, Rng& g) {
+template <class G>
+TOR_HD Ray camera_ray(const Camera& c, double s, double t, G& g) {
   V3 rd = random_in_unit_disk(g) * c.lens_radius;
   V3 offset = c.u * rd.x + c.v * rd.y;
   Ray r;

@@ -1828,6 +1828,65 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// SrvRng -- the chain servers' generator: a pixel's xoshiro256+ stream (rng.nim:58-74), drawn one output at a time as the
+// lanes do, plus a TABLE of what depends on the stream alone.  A server runs ONE chain with all 64 lanes, so
+// random_unit_vector (sampling.nim:51-55: two outputs, a square root and the correctly rounded sin / cos -- 280
+// double-double instructions, a third of a Lambertian bounce) can be evaluated for 64 stream positions at the price of one:
+// at the top of a bounce, when the table is used up, the scalar unit steps a COPY of the (wave-uniform) state 64 times and
+// leaves output k in lane k, and every lane evaluates the vector that starts at its position.  A Lambertian scatter then
+// reads the entry of the running position (v_readlane) and steps the live state twice.  Same operations on the same outputs
+// as the lanes' sequential code: same bits (tests/test_gpu_round3.py: every hand-off test compares the two).
+// ---------------------------------------------------------------------------------------------
+struct SrvRng {
+  Rng st;             // the live state (wave-uniform): every draw steps it, as in the lanes
+  double tx, ty, tz;  // lane k: random_unit_vector drawn at position k of the table (outputs k and k + 1)
+  unsigned i;         // the live state's position in the table (wave-uniform); >= 63: no entry starts here
+};
+constexpr unsigned kSrvTableLast = 62;  // the last position whose two outputs are both in the table
+
+// Builds the table for the 64 positions from the live state on.  ONE call site per copy of serve_chains (top of the
+// bounce loop -- a Lambertian scatter draws its vector first, so the position it reads is the position seen there).
+__device__ __forceinline__ void srv_refill(SrvRng& g) {
+  Rng s = g.st;
+  unsigned lo = 0, hi = 0;
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int k = 0; k < 64; ++k) {  // scalar unit: 64 steps of a copy of the state
+    const uint64_t o = next(s);
+    const bool mine = lane == k;  // (this compiler has no writelane builtin: a compare and two selects per step)
+    lo = mine ? (unsigned)o : lo;
+    hi = mine ? (unsigned)(o >> 32) : hi;
+  }
+  // position k's second output is output k + 1 (lane 63 has none: kSrvTableLast)
+  const unsigned nlo = (unsigned)__shfl_down((int)lo, 1), nhi = (unsigned)__shfl_down((int)hi, 1);
+  const V3 t = random_unit_vector_of(((uint64_t)hi << 32) | lo, ((uint64_t)nhi << 32) | nlo);
+  g.tx = t.x; g.ty = t.y; g.tz = t.z;
+  g.i = 0u;
+}
+
+__device__ __forceinline__ uint64_t next(SrvRng& g) {
+  g.i += 1u;
+  return next(g.st);
+}
+
+__device__ __forceinline__ V3 random_unit_vector(SrvRng& g) {
+  const uint64_t out_a = next(g.st);  // (the live state moves on either way)
+  const uint64_t out_z = next(g.st);
+  const unsigned at = g.i;
+  g.i += 2u;
+  if (at <= kSrvTableLast) {
+    const int k = __builtin_amdgcn_readfirstlane((int)at);
+    auto pick = [&](double v) {
+      const unsigned long long bits = double_to_bits(v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), k);
+      return bits_to_double(((unsigned long long)hi << 32) | (unsigned long long)lo);
+    };
+    return v3(pick(g.tx), pick(g.ty), pick(g.tz));
+  }
+  return random_unit_vector_of(out_a, out_z);  // (not reached from serve_chains: it refills in front of every bounce that would)
+}
+
+// ---------------------------------------------------------------------------------------------
 // serve_chains -- the SERVER side of the SEED_PIXEL chain hand-off, inside integrate_kernel<0, A, W, 1, 1>.
 //
 // A server is a whole wave that continues ONE pixel chain at a time from the state a lane pushed at a sample boundary
@@ -1949,7 +2008,10 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
     unsigned long long pf_query = 0, pf_shade[3] = {0, 0, 0}, pf_miss = 0, pf_setup = 0, pf_n[3] = {0, 0, 0}, pf_nmiss = 0, pf_rounds = 0, pf_cand = 0;
     const unsigned long long pf_begin = __builtin_readcyclecounter();
 #endif
-    Rng rng{rec[1], rec[2], rec[3], rec[4]};
+    SrvRng rng;
+    rng.st = Rng{rec[1], rec[2], rec[3], rec[4]};
+    rng.tx = rng.ty = rng.tz = 0.0;
+    rng.i = 64u;  // no table yet: the first bounce builds one
     V3 acc = v3(bits_to_double(rec[5]), bits_to_double(rec[6]), bits_to_double(rec[7]));
     const unsigned lrow = pl / (unsigned)p.ncols;
     const int col = (int)(pl - lrow * (unsigned)p.ncols);
@@ -1976,6 +2038,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
       pf_setup += __builtin_readcyclecounter() - pf_s0;
 #endif
       for (int depth = 0; depth < p.max_depth; ++depth) {
+        if (rng.i > kSrvTableLast) srv_refill(rng);  // (the only call site: see SrvRng)
         // ---- closest hit (hittables_lists.nim:48-55), boxes and candidates split across the lanes ----
         chain_its += 1;
 #ifdef TOR_SERVE_PROF
