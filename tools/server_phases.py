@@ -42,5 +42,9 @@ for name in ("lambertian", "metal", "dielectric"):
     print(f"  shade {name:10s}              {v[name] / max(n, 1):8.1f}   x {n} ({100.0 * n / bounces:.1f} % of the bounces)")
 print(f"  miss -> sky                     {v['miss'] / max(v['n_miss'], 1):8.1f}   x {v['n_miss']} ({100.0 * v['n_miss'] / bounces:.1f} %)")
 print(f"  camera ray of a new sample      {v['setup'] / max(v['samples'], 1):8.1f}   x {v['samples']}")
+if v.get("q_slab", 0):
+    q = [v[k] / bounces for k in ("q_slab", "q_slots", "q_load", "q_test", "q_min")]
+    print(f"  inside the query (make prof PROF_LEVEL=2; the stamps serialise, the sum exceeds the un-stamped query): ray set-up + slab tests + ballot {q[0]:.0f}, "
+          f"candidate slots {q[1]:.0f}, record loads {q[2]:.0f}, float64 tests {q[3]:.0f}, minimum + winner {q[4]:.0f}")
 print(f"  share of the ticks: query {100.0 * v['query'] / v['total']:.1f} %, shading {100.0 * (v['lambertian'] + v['metal'] + v['dielectric']) / v['total']:.1f} %, "
       f"sky {100.0 * v['miss'] / v['total']:.1f} %, camera {100.0 * v['setup'] / v['total']:.1f} %")

@@ -1045,7 +1045,7 @@ int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]) {
 #ifdef TOR_SERVE_PROF
   // profiling build (make SERVE_PROF=1, tools/server_phases.py): shader-clock ticks per phase of the served bounces
   std::fprintf(stderr, "serve_prof query %llu lambertian %llu metal %llu dielectric %llu miss %llu setup %llu n_lambertian %llu n_metal %llu n_dielectric %llu "
-               "n_miss %llu rounds %llu candidates %llu total %llu samples %llu\n", h[81], h[82], h[83], h[84], h[85], h[86], h[87], h[88], h[89], h[90], h[91], h[92], h[93], h[94]);
+               "n_miss %llu rounds %llu candidates %llu total %llu samples %llu q_slab %llu q_slots %llu q_load %llu q_test %llu q_min %llu\n", h[81], h[82], h[83], h[84], h[85], h[86], h[87], h[88], h[89], h[90], h[91], h[92], h[93], h[94], h[75], h[76], h[77], h[78], h[79]);
 #endif
   return TOR_OK;
 }
