@@ -136,9 +136,11 @@ TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v ocx, f2v ocy
 // itself inflated by 1e-6 relative around the swept spheres).  The ray side: o^ = fl(o - P) is off by <= u |o-P|, and
 // fl((lo, hi) - o^) adds <= u (|lo| + |o^|): both are absorbed by testing the box inflated by e = 3 u (|o-P| + max|box|)
 // on every side, folded into the per-lane addend (-o^ - e, -o^ + e).  What remains is relative: the entry / exit
-// parameters carry <= 2.5 u (rounding of d, of 1/d and of the product), so `t_in <= t_out (1 + 2^-20)` keeps every box
-// whose exact test passes.  NaN (0 * inf on an axis the ray is parallel to, or a NaN padding box) is dropped by
-// min/max exactly as in the float64 test.
+// parameters carry <= 2.5 u (rounding of d, of 1/d and of the product).  A relative error delta of t = (b - o)/d is the
+// error of a plane moved by |delta| |b - o| <= 2.6 u (|o-P| + max|box|), so it is paid in the same coin: the inflation is
+// e = 6 u (|o-P| + max|box|) (3 u + 2.6 u, rounded up) and the test is the plain `t_in <= t_out` -- one instruction per box
+// less than the relative slack `t_out (1 + 2^-20)` of rounds 1-2 cost.  NaN (0 * inf on an axis the ray is parallel to, or
+// a NaN padding box) is dropped by min/max exactly as in the float64 test.
 struct BoxRay32 {
   f2v ax, ay, az;  // (-o^ - e, -o^ + e) / d^ per axis (the quotient is formed per ray, see slab_bit32)
   f2v ix, iy, iz;  // 1/d^ per axis, both halves
@@ -146,7 +148,7 @@ struct BoxRay32 {
 
 TOR_HD BoxRay32 make_box_ray32(const RayF32& r, float bmax) {
   BoxRay32 b;
-  const float e = 3.0f * kU32 * (r.ro + bmax);
+  const float e = 6.0f * kU32 * (r.ro + bmax);
   // An axis the ray is (nearly) parallel to -- |1/d^| = inf or so large that the per-ray product could overflow --
   // must not constrain: in the fused form box * inf + (-o^) * inf is inf - inf = NaN exactly when the origin lies
   // between the planes, and max(-inf, NaN) would then report "leaves before it enters".  Such an axis gets
@@ -168,7 +170,7 @@ TOR_HD BoxRay32 make_box_ray32(const RayF32& r, float bmax) {
 TOR_HD unsigned slab_bit32(const BoxRay32& b, f2v bx, f2v by, f2v bz) {
   // t = (box - o^ -+ e) / d^ as ONE fused multiply-add per axis: box * (1/d^) + ((-o^ -+ e) * (1/d^)), the second product
   // formed once per ray.  Against the two-step form this moves one rounding: the per-ray product carries u |o^ +- e| |1/d^|,
-  // which is a box-coordinate error of u (|o-P| + e) -- inside the inflation e = 3 u (|o-P| + max|box|), whose budget
+  // which is a box-coordinate error of u (|o-P| + e) -- inside the first 3 u (|o-P| + max|box|) of the inflation, whose budget
   // so far only spent u |o-P| (rounding of o^) + u (|box| + |o^|) (the subtraction, now exact inside the fma).  With
   // d^ = 0 an axis gives inf - inf = NaN more often than before (whenever box and origin terms differ in sign); NaN is
   // dropped by min/max, i.e. that axis stops constraining: conservative.
@@ -178,7 +180,7 @@ TOR_HD unsigned slab_bit32(const BoxRay32& b, f2v bx, f2v by, f2v bz) {
                                      __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
   const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)),
                                       __builtin_fmaxf(tz0, tz1));
-  return (t_in <= __builtin_fmaf(t_out, 0x1p-20f, t_out)) ? 1u : 0u;
+  return (t_in <= t_out) ? 1u : 0u;
 }
 
 // Host-side per-object constant k (rounded up) and eligibility; used by tor_scene.cpp and the self test.

@@ -182,6 +182,16 @@ __device__ __forceinline__ unsigned push_bit(unsigned m, int t) {
   return __builtin_amdgcn_alignbit(m, (unsigned)t, 31);
 }
 
+// m = (m << 1) | c with the condition still in its scalar register pair: v_cmp ... + ONE v_addc_co_u32 (m + m + carry-in)
+// instead of v_cmp, v_cndmask, v_or (+ a shift every other time) -- the compiler turns `m + m + c` back into those.
+__device__ __forceinline__ unsigned push_cond(unsigned m, bool c) {
+  const unsigned long long mask = __ballot(c);
+  unsigned long long carry_out;
+  unsigned r;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(mask));
+  return r;
+}
+
 // chain servers (defined after the kernel): whole waves that continue pixel chains handed over by the lanes
 template <int ARITH>
 __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated);
@@ -685,8 +695,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 unsigned m = 0;
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j)
-                  m = (m << 1) | slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
-                                            (f2v){rec[8 * j + 4], rec[8 * j + 5]});
+                  m = push_cond(m, slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
+                                            (f2v){rec[8 * j + 4], rec[8 * j + 5]}) != 0u);
                 rec += 8 * kBlock;
                 unsigned wild = r32.wild;  // (see below: never into the padding super boxes)
                 if (seg_kind == 4) {
@@ -701,8 +711,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               unsigned m = 0;
 #pragma unroll
               for (int j = 0; j < kBlock; ++j)
-                m = (m << 1) | slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
-                                          (f2v){rec[8 * j + 4], rec[8 * j + 5]});
+                m = push_cond(m, slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
+                                          (f2v){rec[8 * j + 4], rec[8 * j + 5]}) != 0u);
               rec += 8 * kBlock;
               // a 'wild' ray (outside the float32 filter's guarded ranges) enters every box -- every REAL box: the
               // padding entries of the super-box segment have no block boxes or records behind them
@@ -1019,8 +1029,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                     auto child32 = [&](auto cb) {
 #pragma unroll 4
                       for (int j = 0; j < kBlock; ++j)
-                        mc = (mc << 1) | slab_bit32(ob, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
-                                                    (f2v){cb[8 * j + 4], cb[8 * j + 5]});
+                        mc = push_cond(mc, slab_bit32(ob, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
+                                                    (f2v){cb[8 * j + 4], cb[8 * j + 5]}) != 0u);
                     };
                     if (p.bnd32_lds_floats > 0) child32(bnd32_lds + (size_t)rec * (8 * kBlock));
                     else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
@@ -1098,8 +1108,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               auto child32 = [&](auto cb) {
 #pragma unroll 4
                 for (int j = 0; j < kBlock; ++j)
-                  mc = (mc << 1) | slab_bit32(b32, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
-                                              (f2v){cb[8 * j + 4], cb[8 * j + 5]});
+                  mc = push_cond(mc, slab_bit32(b32, (f2v){cb[8 * j + 0], cb[8 * j + 1]}, (f2v){cb[8 * j + 2], cb[8 * j + 3]},
+                                              (f2v){cb[8 * j + 4], cb[8 * j + 5]}) != 0u);
               };
               if (p.bnd32_lds_floats > 0) child32(bnd32_lds + (size_t)rec * (8 * kBlock));
               else child32((gfptr)(uintptr_t)p.bnd32 + (size_t)rec * (8 * kBlock));
