@@ -62,6 +62,13 @@ def test_configs2_full_size(tor, oracle, ref_scene, ref_camera):
     for r in rows:
         want = oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=1, arith=0, rows=(r, r + 1), col_block=8).pixels[r]
         _exact(p[r], want)
+    # ... and against the oracle's PINNED mode (LIBM: the one that reproduces the reference PNG at C1) at this size too: the
+    # portable math twin the rows above are bit-equal to differs from it by last-bit events only
+    for r in (540, 731):
+        pinned = oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=0, arith=0, rows=(r, r + 1), col_block=8).pixels[r]
+        err = float(np.max(np.abs(p[r] - pinned)))
+        print(f"configs[2] row {r} GPU vs oracle(LIBM): max |delta| = {err:.3e}")
+        assert err < 1e-12
     ctx.close()
 
 

@@ -1295,7 +1295,7 @@ int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double
       const double* sg = &lay.segs[8 * (size_t)s];
       const int kind = (int)sg[0];
       if (kind < 5) continue;
-      const int begin = (int)sg[1], count = (int)sg[2], block0 = (int)sg[3];
+      const int begin = (int)sg[1], count = (int)sg[2] & 0xffffff, block0 = (int)sg[3];
       const double f64 = kind == 5 ? 0.0 : (time[r] - sg[4]) / sg[5];
       const tor::SegF32 s32 = tor::make_seg_f32(r32, f64, (float)sg[6], (float)sg[7]);
       const int stride = kind == 5 ? 10 : (kind == 6 ? 12 : 16);

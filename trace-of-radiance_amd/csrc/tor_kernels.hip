@@ -604,7 +604,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         while (seg < p.n_segs) {
           const int seg_kind = (int)segs[seg * 8 + 0];
           const int seg_begin = (int)segs[seg * 8 + 1];    // first hot record of the segment
-          const int seg_count = (int)segs[seg * 8 + 2];    // padded to kBlock
+          const int seg_count_word = (int)segs[seg * 8 + 2];
+          const int seg_count = seg_count_word & 0xffffff;   // padded to kBlock
+          const int seg_real = seg_count - (seg_count_word >> 24);  // kinds 0-2: the objects that exist (the last block's tail is padding)
           const int seg_block0 = (int)segs[seg * 8 + 3];   // (first sorted index) / kBlock
           if (seg_kind == 0) {
             // one base pointer per block, immediate offsets inside it, and the next record is
@@ -614,13 +616,26 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             if (kScreen) screen_margins(scr_s1 + segs[seg * 8 + 6], scr_d1, a, scr_negmu, scr_am);
             for (; i < seg_count; i += kBlock) {
               unsigned m = 0;
+              const int n_live = seg_real - i;  // (wave-uniform)
+              if (n_live >= kBlock) {
 #pragma unroll
-              for (int j = 0; j < kBlock; ++j) {
-                const double c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-                n0 = rec[4 * (j + 1) + 0]; n1 = rec[4 * (j + 1) + 1];   // next object (the arrays carry one
-                n2 = rec[4 * (j + 1) + 2]; n3 = rec[4 * (j + 1) + 3];   // record of slack past the last block)
-                if (kScreen) m = push_bit(m, screen_filter(ox - c0, oy - c1, oz - c2, dx, dy, dz, a, scr_negmu, scr_am, c3));
-                else m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0, c1, c2, c3));
+                for (int j = 0; j < kBlock; ++j) {
+                  const double c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+                  n0 = rec[4 * (j + 1) + 0]; n1 = rec[4 * (j + 1) + 1];   // next object (the arrays carry one
+                  n2 = rec[4 * (j + 1) + 2]; n3 = rec[4 * (j + 1) + 3];   // record of slack past the last block)
+                  if (kScreen) m = push_bit(m, screen_filter(ox - c0, oy - c1, oz - c2, dx, dy, dz, a, scr_negmu, scr_am, c3));
+                  else m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0, c1, c2, c3));
+                }
+              } else {
+                // the segment's last block: only its real objects (a padding record costs as much as a sphere; the four
+                // always-tested spheres of a culling layout are half a block)
+#pragma unroll 1
+                for (int j = 0; j < n_live; ++j) {
+                  const double c0 = rec[4 * j + 0], c1 = rec[4 * j + 1], c2 = rec[4 * j + 2], c3 = rec[4 * j + 3];
+                  if (kScreen) m = push_bit(m, screen_filter(ox - c0, oy - c1, oz - c2, dx, dy, dz, a, scr_negmu, scr_am, c3));
+                  else m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0, c1, c2, c3));
+                }
+                m <<= (unsigned)(kBlock - n_live);
               }
               rec += 4 * kBlock;
               q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
@@ -765,11 +780,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
               for (; i < seg_count; i += kBlock) {
                 unsigned m = 0;
-#pragma unroll
-                for (int j = 0; j < kBlock; ++j) {
-                  const double c0x = n0, c0y = n1, c0z = n2, r2 = n3, dcy = n4;
-                  n0 = rec[6 * (j + 1) + 0]; n1 = rec[6 * (j + 1) + 1]; n2 = rec[6 * (j + 1) + 2];
-                  n3 = rec[6 * (j + 1) + 3]; n4 = rec[6 * (j + 1) + 4];
+                const int n_live = seg_real - i;  // (wave-uniform)
+                auto test_y = [&](double c0x, double c0y, double c0z, double r2, double dcy) {
                   if (kScreen) {
                     // (centre folded into oc: o - (c0 + dc f) as fma(-f, dc, o - c0), one scalar operand per instruction)
                     m = push_bit(m, screen_filter(ox - c0x, fma_(neg_f, dcy, oy - c0y), oz - c0z, dx, dy, dz, a, scr_negmu, scr_am, r2));
@@ -777,6 +789,19 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                     const double cy = (ARITH != 1) ? c0y + dcy * f : fma_(dcy, f, c0y);
                     m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, c0x, cy, c0z, r2));
                   }
+                };
+                if (n_live >= kBlock) {
+#pragma unroll
+                  for (int j = 0; j < kBlock; ++j) {
+                    const double c0x = n0, c0y = n1, c0z = n2, r2 = n3, dcy = n4;
+                    n0 = rec[6 * (j + 1) + 0]; n1 = rec[6 * (j + 1) + 1]; n2 = rec[6 * (j + 1) + 2];
+                    n3 = rec[6 * (j + 1) + 3]; n4 = rec[6 * (j + 1) + 4];
+                    test_y(c0x, c0y, c0z, r2, dcy);
+                  }
+                } else {  // the last block: only its real objects
+#pragma unroll 1
+                  for (int j = 0; j < n_live; ++j) test_y(rec[6 * j + 0], rec[6 * j + 1], rec[6 * j + 2], rec[6 * j + 3], rec[6 * j + 4]);
+                  m <<= (unsigned)(kBlock - n_live);
                 }
                 rec += 6 * kBlock;
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
@@ -786,8 +811,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             } else {
               for (; i < seg_count; i += kBlock) {
                 unsigned m = 0;
+                const int n_live = seg_real - i;  // (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j) {
+                  if (j >= n_live) { m <<= 1; continue; }  // padding of the last block
                   const int k = seg_begin + i + j;
                   const double c0x = mov[8 * k + 0], c0y = mov[8 * k + 1], c0z = mov[8 * k + 2];
                   const double dcx = mov[8 * k + 4], dcy = mov[8 * k + 5], dcz = mov[8 * k + 6];

@@ -202,7 +202,8 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
       const TorSphere& s = objs[statics[k]].u.sphere;
       reach = std::fmax(reach, norm3(s.center.x, s.center.y, s.center.z) + std::fabs(s.radius));
     }
-    out.segs.insert(out.segs.end(), {0.0, 0.0, (double)n_stat_p, 0.0, 0.0, 0.0, up(reach), 0.0});
+    // (segs[2] of kinds 0-2: padded count | padding records << 24 -- the kernel tests only the real objects of the last block)
+    out.segs.insert(out.segs.end(), {0.0, 0.0, (double)(n_stat_p | ((n_stat_p - statics.size()) << 24)), 0.0, 0.0, 0.0, up(reach), 0.0});
     for (size_t k = 0; k < statics.size(); ++k) {
       const TorSphere& s = objs[statics[k]].u.sphere;
       out.stat[4 * k + 0] = s.center.x; out.stat[4 * k + 1] = s.center.y; out.stat[4 * k + 2] = s.center.z;
@@ -224,7 +225,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
       reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
       travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
     }
-    out.segs.insert(out.segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)cnt_p,
+    out.segs.insert(out.segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)(cnt_p | ((cnt_p - g.ids.size()) << 24)),
                                      (double)(sorted / kPad), t0, dt, up(reach), up(travel)});
     for (size_t k = 0; k < g.ids.size(); ++k) {
       const TorMovingSphere& s = objs[g.ids[k]].u.moving_sphere;
