@@ -191,6 +191,9 @@ enum {
  *   TOR_DEFAULT_ACCEL = 0..3  TOR_ACCEL_* bits.  Unset: 3 -- both exact accelerations are ON for tor_render()
  *                             (bit-identical canvases by construction, parity tests and differential fuzzing);
  *                             0 restores the reference's float64 brute force.
+ *   TOR_SCREEN = 0            (float64 brute force only) every ray x object through the reference's unfused discriminant;
+ *                             unset: the object loop is a conservative FMA screen of the same quadratic and only its
+ *                             candidates see the unfused operations -- same canvas (csrc/tor_screen.hpp), read at context creation
  *   TOR_DEVICES = "all" | "0,1,2,3"   render on several GPUs (TorOptions.device_count / devices)
  *   TOR_GATHER  = rccl | peer | host  (TorOptions.gather)
  * The device scene is cached: a call whose object list is byte-identical to the previous call's (on that
