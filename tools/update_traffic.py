@@ -14,7 +14,8 @@ CONFIGS = {   # key in traffic.json -> (summary file, seeding template argument)
     "1920x1080x1000:sample:strict": ("r3_c3_summary.txt", 1),
     "1920x1080x100:sample:strict:f32": ("r1_accel_f32_summary.txt", 1),
     "1920x1080x100:sample:strict:blocks": ("r1_accel_blocks_summary.txt", 1),
-    "1920x1080x100:sample:strict:blocks+f32": ("r2_c2_accel3_summary.txt", 1),
+    "1920x1080x100:sample:strict:blocks+f32": ("r3_c2_accel3_summary.txt", 1),
+    "1920x1080x1000:sample:strict:blocks+f32": ("r3_c3_accel3_summary.txt", 1),
     "1920x1080x100:pixel:strict:blocks+f32": ("r3_c2_pixel_default_summary.txt", 0),
     "1920x1080x1000:pixel:strict:blocks+f32": ("r3_c3_pixel_default_summary.txt", 0),
 }
