@@ -392,3 +392,34 @@ def test_fma_screen_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
         ctx.close()
     assert stats["on"].hit_queries == stats["off"].hit_queries and stats["on"].samples == stats["off"].samples
     assert stats["off"].candidates <= stats["on"].candidates <= 1.6 * stats["off"].candidates, (stats["on"].candidates, stats["off"].candidates)
+
+
+def test_servers_walk_the_box_bits_when_a_ray_enters_64_boxes_or_more(tor):
+    """serve_chains compacts the boxes a ray can touch with lane permutes -- for up to 63 of them.  A `wild` ray (outside the
+    float32 test's guarded ranges) enters every box; with more than 63 blocks the servers fall back to the walk over the set
+    bits.  700 small spheres = 88 blocks on one culling level, camera 3e6 units away (|o - P| > 2^20: every camera ray is
+    wild): hand-off on == off == the float64 brute force, with chains really served."""
+    import torch
+    rng = np.random.default_rng(11)
+    recs = [[0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0]]
+    for i in range(700):
+        x, z = rng.uniform(-14, 14, 2)
+        mat = [0, 1, 2][i % 3]
+        if i % 2:
+            recs.append([0, x, .2, z, x, .2, z, 0, 1, .2, mat, .6, .5, .4, 0.2, 1.5])
+        else:
+            recs.append([1, x, .2, z, x, .2 + rng.uniform(0, .5), z, 0.0, 1.0, .2, mat, .3, .7, .4, 0.1, 1.5])
+    scene = tor.Scene.from_records(np.asarray(recs, dtype=np.float64))
+    dist = 3.0e6
+    look_from = (dist * 0.8, dist * 0.3, dist * 0.52)
+    cam = tor.camera(look_from=look_from, look_at=(0, 0.5, 0), vertical_field_of_view=float(np.degrees(2 * np.arctan(9.0 / dist))),
+                     aperture=0.0, focus_distance=dist)
+    h, w, spp = 36, 64, 40
+    brute, _ = _render_with_env(tor, scene, cam, h, w, spp, {}, seeding=tor.SEED_PIXEL, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+    # (the hand-off belongs to TorOptions.pixel_kernel = AUTO; TOR_MIGRATE=0 + LANE is the lane kernel alone)
+    off, c0 = _render_with_env(tor, scene, cam, h, w, spp, {"TOR_MIGRATE": "0"}, seeding=tor.SEED_PIXEL, accel=3, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+    on, c1 = _render_with_env(tor, scene, cam, h, w, spp, {"TOR_PUSH_THETA": "0.01", "TOR_CHAIN_THETA": "0.01", "TOR_FLOOR_THETA": "0.01"},
+                              seeding=tor.SEED_PIXEL, accel=3)
+    assert float(brute.abs().sum()) > 0.0 and float(brute.std()) > 0.0     # the camera does see the scene
+    assert torch.equal(off, brute) and torch.equal(on, brute), (c0, c1)
+    assert c0["pushed"] == 0 and c1["pushed"] > 0 and c1["served"] == c1["pushed"]
