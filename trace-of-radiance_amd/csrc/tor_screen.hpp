@@ -7,7 +7,7 @@ namespace tor {
 
 // ARITH 2 -- the reference's results behind a conservative FMA SCREEN.  The wave-uniform object loop only decides which
 // objects become CANDIDATES; every candidate is re-tested by the deferred pass with the reference's own operations in
-// the reference's order (exact_hit below: spheres.nim:29-48 unfused), and a candidate that fails there costs nothing but
+// the reference's order (exact_hit in tor_kernels.hip: spheres.nim:29-48 unfused), and a candidate that fails there costs nothing but
 // time.  So the loop may use any test that never drops an object the reference's test keeps.  This one evaluates the same
 // quadratic with FMAs -- 11 / 12 / 14 float64 instructions for a static / y-only moving / moving sphere instead of
 // 17 / 19 / 23 -- and leans it towards "keep" by more than the two evaluations can differ:
