@@ -144,7 +144,9 @@ def from_profile(W, H, spp, seeding, arith, accel="none"):
 # ---------------------------------------------------------------------------------------------------------
 def pmc_child(spec):
     """Child of live_traffic(): one launch through the bare C ABI (ctypes only, no torch)."""
-    W, H, spp, depth, seeding, arith, accel = (int(x) for x in spec.split(","))
+    vals = [int(x) for x in spec.split(",")]
+    W, H, spp, depth, seeding, arith, accel = vals[:7]
+    shard_index, shard_count, row_tile = (vals[7:10] if len(vals) >= 10 else (0, 1, 1))
     os.environ["TOR_NO_TORCH"] = "1"
     tor = importlib.import_module("trace-of-radiance_amd")
     scene, cam = tor.random_scene(0xFACADE), tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
@@ -153,11 +155,12 @@ def pmc_child(spec):
     # host-canvas leg is in.  The first launch of a process (fresh allocations) fetches the canvas once from HBM and writes it
     # back as 64-byte lines on top: +65 MB read, +123 MB written at 1080p (profiles/r3_traffic_reconcile.txt)
     for _ in range(2):
-        tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, arith=arith, accel=accel))
+        tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, arith=arith, accel=accel, shard_index=shard_index,
+                                                                  shard_count=shard_count, row_tile=row_tile))
     print("pmc-child done", float(cv.pixels.mean()))
 
 
-def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=240):
+def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=240, shard=(0, 1, 1)):
     """HBM bytes of ONE integrate_kernel launch of this configuration, from two separate rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots'), corrected as the
     guide's HBM section says: FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE is
@@ -170,7 +173,7 @@ def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=240):
     out = {}
     base = tempfile.mkdtemp(prefix="tor_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", TOR_NO_TORCH="1")
-    spec = f"{W},{H},{spp},{depth},{seeding},{arith},{accel}"
+    spec = f"{W},{H},{spp},{depth},{seeding},{arith},{accel},{shard[0]},{shard[1]},{shard[2]}"
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(base, counter)
@@ -339,48 +342,79 @@ def algorithmic_flops_per_sample(scene, tor, queries_per_sample=2.6022):
 def bench_single_process_multi_device(args, tor):
     """`python bench.py --gpus N` without torchrun: ONE process drives N devices through the drop-in itself
     (tor_render_opt with TorOptions.devices: a host thread + stream per device, row-cyclic shards, framebuffer
-    gather) -- the path a Nim host takes.  Timed region = SURVEY 8(d): host canvas in, host canvas out."""
+    gather) -- the path a Nim host takes.  Timed region = SURVEY 8(d): host canvas in, host canvas out.
+    The line is self-contained: CPU baseline timed BEFORE the devices are busy, kernel-level roofline from
+    the per-device HIP events of the launches, live PMC traffic of one shard's launch, the gather leg and the RCCL
+    communicator's rank count, and the N = 1 value of the same invocation."""
     import torch
     H, W, N = args.height, args.width, args.gpus
     spp = frame_spp(args, N)
     n_dev = max(torch.cuda.device_count(), 1)
     devices = [k % n_dev for k in range(N)]
+    n_distinct = len(set(devices))
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds)   # the host cores are idle: no device work yet
     scene = tor.random_scene(0xFACADE)
     cam = tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
     arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
-    opt = tor.make_options(seeding=seeding, arith=arith, accel=ACCEL_BITS[args.accel], row_tile=args.row_tile, devices=devices)
+    accel = ACCEL_BITS[args.accel]
+    opt = tor.make_options(seeding=seeding, arith=arith, accel=accel, row_tile=args.row_tile, devices=devices)
     cv = tor.new_canvas(H, W, spp, 2.2)
     for _ in range(args.warmup):
         tor.render(cv, cam, scene.list(), args.depth, opt)
+    k_ms_steps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tor.render(cv, cam, scene.list(), args.depth, opt)
+        k_ms_steps.append(tor.last_device_kernel_ms())
     elapsed = time.perf_counter() - t0
     timing = tor.last_render_timing()
     note = tor.last_note()
-    verified = None
-    if args.verify:
-        one = tor.new_canvas(H, W, spp, 2.2)
-        tor.render(one, cam, scene.list(), args.depth, tor.make_options(seeding=seeding, arith=arith, accel=ACCEL_BITS[args.accel]))
-        import numpy as np
-        verified = bool(np.array_equal(one.pixels, cv.pixels))
-        if not verified:
-            raise SystemExit("multi-device canvas differs from the single-device canvas")
+    info = tor.last_gather_info()
     value = H * W * spp * args.steps / elapsed / 1e6
-    # roofline of the whole step (the library's per-device kernel events are not visible through the drop-in): the
-    # algorithmic float64 work of the frame (SURVEY 8d, queries per sample as measured at N = 1) over the step time, against N devices
+    # ---- the N = 1 value of this very invocation (same frame, device 0 alone, same host-canvas region) ----
+    aux = max(1, min(args.aux_steps, args.steps))
+    one = tor.new_canvas(H, W, spp, 2.2)
+    opt1 = tor.make_options(seeding=seeding, arith=arith, accel=accel, device=devices[0])
+    tor.render(one, cam, scene.list(), args.depth, opt1)
+    t1 = time.perf_counter()
+    for _ in range(aux):
+        tor.render(one, cam, scene.list(), args.depth, opt1)
+    dt1 = time.perf_counter() - t1
+    n1_value = H * W * spp * aux / dt1 / 1e6
+    import numpy as np
+    verified = bool(np.array_equal(one.pixels, cv.pixels))
+    if args.verify and not verified:
+        raise SystemExit("multi-device canvas differs from the single-device canvas")
+    # ---- kernel-level roofline: every device's integrate_kernel launch (HIP events on its own stream), averaged over the steps;
+    #      the job's kernel phase ends with the slowest device ----
+    per_dev = [sum(st[k] for st in k_ms_steps) / len(k_ms_steps) for k in range(N)] if k_ms_steps and all(len(st) == N for st in k_ms_steps) else []
+    shard_rows = [len(tor.shard_rows(H, args.row_tile, k, N)) for k in range(N)]
     fps = algorithmic_flops_per_sample(scene, tor)
-    tflops = value * 1e6 * fps / 1e12
-    roof = {"bound": "valu_fp64", "kernel": "tor::integrate_kernel on each of the N devices (whole step: render + gather + D2H)",
-            "achieved": round(tflops, 3), "peak": PEAK_FP64_VECTOR_TFLOPS * N, "unit": "TFLOP/s",
-            "frac": round(tflops / (PEAK_FP64_VECTOR_TFLOPS * N), 4), "frac_of_nofma_peak": round(tflops / (PEAK_FP64_NOFMA_TFLOPS * N), 4),
-            "flops_per_sample": round(fps, 1), "traffic": None,
-            "note": "step-level figure; the kernel-level roofline (HIP events, PMC traffic) is the N = 1 line's"}
-    cpu = None
-    if not args.no_cpu_baseline and n_dev == 1:
-        # (every listed ordinal is the same GPU: a 1-GPU box emulating N devices -- the host's cores are free for the baseline)
-        cpu = cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds)
+    roof = {"bound": "valu_fp64", "kernel": "tor::integrate_kernel (one launch per device and step)"}
+    if per_dev and max(per_dev) > 0:
+        k_max = max(per_dev)
+        # one launch per device entry, side by side: the job's kernel phase is the slowest launch (entries that repeat an ordinal
+        # share that GPU's issue slots -- their launches overlap, the longest of them spans the phase); against the GPUs that exist
+        tflops = H * W * spp * fps / (k_max * 1e-3) / 1e12
+        peak = PEAK_FP64_VECTOR_TFLOPS * n_distinct
+        roof.update({"achieved": round(tflops, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                     "frac_of_nofma_peak": round(tflops / (PEAK_FP64_NOFMA_TFLOPS * n_distinct), 4),
+                     "kernel_ms_per_device": [round(m, 3) for m in per_dev], "kernel_ms": round(k_max, 3), "launches_averaged": len(k_ms_steps),
+                     "flops_per_sample": round(fps, 1)})
+    traffic, traffic_note = None, "skipped (--no-pmc)" if args.no_pmc else None
+    if not args.no_pmc:
+        traffic, traffic_note = live_traffic(W, H, spp, args.depth, seeding, arith, accel, shard=(0, N, args.row_tile))
+    roof["traffic"] = traffic["bytes"] if traffic else None
+    roof["traffic_detail"] = traffic if traffic else traffic_note
+    roof["traffic_scope"] = f"one launch = shard 0 of {N} ({shard_rows[0]} rows)"
+    roof["hbm"] = {"bound": "hbm", "algorithmic_bytes_per_launch": shard_rows[0] * W * 24.0 * (2 if seeding == tor.SEED_SAMPLE else 1) + 64e3,
+                   "peak": PEAK_HBM_GBPS, "unit": "GB/s"}
+    if per_dev and per_dev[0] > 0:
+        roof["hbm"]["achieved"] = round(roof["hbm"]["algorithmic_bytes_per_launch"] / (per_dev[0] * 1e-3) / 1e9, 4)
+        roof["hbm"]["frac"] = round(roof["hbm"]["achieved"] / PEAK_HBM_GBPS, 8)
     print(json.dumps({
         "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(value, 2),
         "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -391,9 +425,13 @@ def bench_single_process_multi_device(args, tor):
                    "parallelism": f"ONE process, tor_render_opt with devices={devices}: row tiles of {args.row_tile} dealt to {N} "
                                   f"device contexts, framebuffer gather inside the library ({note})",
                    "timed_region": "SURVEY 8(d): host canvas in/out (scene cached after the first call)"},
+        "gather": {"leg": info["leg"], "rccl_ranks": info["rccl_ranks"], "devices": info["devices"], "distinct_gpus": n_distinct, "note": note},
+        "rccl_ranks": info["rccl_ranks"],
+        "single_gpu_same_run": {"value": round(n1_value, 2), "unit": "Msamples/s", "steps": aux, "ms_per_step": round(dt1 / aux * 1e3, 3),
+                                "speedup": round(value / n1_value, 3), "region": "the same frame and region on devices[0] alone"},
         "last_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
         "canvas_identical_to_single_device": verified, "roofline": roof,
-        "cpu_baseline": cpu if cpu is not None else {"value": None, "note": "reported by the N = 1 line (python bench.py)"}}), flush=True)
+        "cpu_baseline": cpu if cpu is not None else {"value": None, "note": "skipped (--no-cpu-baseline)"}}), flush=True)
 
 
 def main():
@@ -448,6 +486,7 @@ def main():
     # ---- N > 1: the framebuffer gather.  Preferred: RCCL inside the library (tor_render_gather_device). ----
     gather_kind = None
     tframe = None
+    rccl_ranks = None
     if world > 1:
         gather_kind = "torch.distributed all_gather (RCCL)" if backend == "nccl" else f"torch.distributed all_gather ({backend})"
         lib_ok = False
@@ -455,7 +494,24 @@ def main():
             try:
                 uid = [tor.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init_rank(uid[0], rank, world)
+                # watchdog: ncclCommInitRank that never returns (the usual failure on a fresh node) must not hang the run --
+                # it runs in a helper thread (ctypes releases the GIL) and is abandoned at the deadline
+                import threading
+                box = {}
+
+                def _init():
+                    try:
+                        ctx.comm_init_rank(uid[0], rank, world)
+                        box["ok"] = True
+                    except Exception as e:  # noqa
+                        box["err"] = e
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("TOR_BENCH_RCCL_INIT_S", "120")))
+                if th.is_alive():
+                    raise RuntimeError("ncclCommInitRank did not return within the deadline")
+                if "err" in box:
+                    raise box["err"]
                 lib_ok = True
             except Exception as e:  # noqa
                 print(f"[bench rank {rank}] library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
@@ -469,6 +525,13 @@ def main():
                     th, tw = 64, 96
                     small = torch.zeros((th, tw, 3), dtype=torch.float64, device="cuda")
                     ctx.render_gather_device(cam, th, tw, 2, 2.2, 8, opt, 0, small.data_ptr(), stream)
+                    # (a gather that does not complete is aborted at the deadline: poll, do not synchronise)
+                    t_dead = time.perf_counter() + float(os.environ.get("TOR_BENCH_RCCL_CHECK_S", "60"))
+                    while not torch.cuda.current_stream().query():
+                        if time.perf_counter() > t_dead:
+                            ctx.comm_abort()
+                            raise RuntimeError("the library's RCCL gather did not complete within the deadline; communicator aborted")
+                        time.sleep(0.002)
                     torch.cuda.synchronize()
                     ok = 1
                     if rank == 0:
@@ -485,9 +548,12 @@ def main():
                 lib_ok = bool(flag.item())
                 if not lib_ok:
                     ctx.comm_destroy()
+        rccl_ranks = None
         if lib_ok:
             gather_kind = "tor_render_gather_device: RCCL send/recv gather to rank 0 inside libtor_mi355x + de-interleave kernel"
+            rccl_ranks = ctx.comm_count()     # ncclCommCount of the communicator that carries the framebuffer
         else:
+            rccl_ranks = dist.get_world_size() if backend == "nccl" else 0
             tdist = importlib.import_module("trace-of-radiance_amd.distributed")
             tframe = tdist.DistributedFrame(tdist.ShardPlan(H, args.row_tile, world), W, rank, torch.device("cuda"))
             assert list(tframe.my_rows) == list(my_rows)
@@ -519,8 +585,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # dominant kernel: integrate_kernel, per-launch HIP events on the launch stream
+    # dominant kernel: integrate_kernel, per-launch HIP events on the launch stream; N > 1: every rank's mean, the job's
+    # kernel phase is the slowest rank's
     k_ms, k_n = ctx.kernel_ms_mean(args.steps)
+    k_ms_ranks = [k_ms]
+    if world > 1:
+        allk = torch.zeros(world, dtype=torch.float64, device="cuda")
+        allk[rank] = k_ms
+        dist.all_reduce(allk, op=dist.ReduceOp.SUM)
+        k_ms_ranks = [float(x) for x in allk.cpu()]
+    # the N = 1 value of this very invocation: rank 0 renders the whole frame alone (the other ranks wait at the barrier below)
+    n1 = None
+    if world > 1:
+        if rank == 0:
+            aux1 = max(1, min(args.aux_steps, args.steps))
+            full1 = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+            o1 = tor.make_options(seeding=seeding, arith=arith, accel=accel)
+            ctx.render_device(cam, H, W, spp, 2.2, args.depth, o1, full1.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(aux1):
+                ctx.render_device(cam, H, W, spp, 2.2, args.depth, o1, full1.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            n1 = {"value": round(H * W * spp * aux1 / dt1 / 1e6, 2), "unit": "Msamples/s", "steps": aux1, "ms_per_step": round(dt1 / aux1 * 1e3, 3),
+                  "kernel_ms": round(ctx.kernel_ms_mean(aux1)[0], 3), "region": "the same frame, resident, on rank 0's GPU alone",
+                  "frame_identical_to_gathered": bool(torch.equal(full1, frame if tframe is None else tframe.frame))}
+            del full1
+        dist.barrier()
 
     verified = None
     if args.verify and world > 1:
@@ -571,6 +663,8 @@ def main():
             }
             del one
         k_rate = local_samples / (k_ms * 1e-3)          # samples/s inside the kernel, this rank
+        if world > 1:                                   # N > 1: the whole frame over the slowest rank's kernel, against N GPUs
+            k_rate = total_samples / (max(k_ms_ranks) * 1e-3) / world
         tflops = k_rate * flops_per_sample / 1e12
         hbm_bytes = len(my_rows) * W * 24.0 * (2 if seeding == tor.SEED_SAMPLE else 1) + 64e3  # canvas write (+ clear in SAMPLE mode) + scene
         traffic, traffic_note = None, "skipped (--no-pmc)" if args.no_pmc else None
@@ -582,7 +676,9 @@ def main():
             "frac": round(tflops / PEAK_FP64_VECTOR_TFLOPS, 4),
             "frac_of_nofma_peak": round(tflops / PEAK_FP64_NOFMA_TFLOPS, 4),
             "nofma_peak": PEAK_FP64_NOFMA_TFLOPS,
-            "flops_per_sample": round(flops_per_sample, 1), "kernel_ms": round(k_ms, 3), "launches_averaged": k_n,
+            "flops_per_sample": round(flops_per_sample, 1), "kernel_ms": round(max(k_ms_ranks), 3), "launches_averaged": k_n,
+            "kernel_ms_per_rank": [round(x, 3) for x in k_ms_ranks] if world > 1 else None,
+            "scope": "per GPU (achieved and peak are one device's; N > 1: the frame's samples / N over the slowest rank's kernel time)",
             "traffic": traffic["bytes"] if traffic else None,
             "traffic_detail": traffic if traffic else traffic_note,
             "executed_live": live,
@@ -624,6 +720,12 @@ def main():
         }
         if verified is not None:
             result["gathered_frame_identical_to_single_process"] = verified
+        if world > 1:
+            result["rccl_ranks"] = rccl_ranks
+            result["gather"] = {"kind": gather_kind, "rccl_ranks": rccl_ranks, "world": world}
+            if n1 is not None:
+                n1["speedup"] = round(value / n1["value"], 3)
+                result["single_gpu_same_run"] = n1
     aux = max(1, min(args.aux_steps, args.steps))
     if rank == 0 and world == 1 and not args.no_host_leg:
         # ---- SURVEY 8(d)'s region: what a Nim caller of render() pays (trace_of_radiance.nim:60-64) ----
@@ -707,15 +809,19 @@ def main():
                                 "ms_per_step": round(dt2 / aux * 1e3, 3),
                                 "note": "TOR_SEED_PIXEL (render.nim:59-67 streams), " +
                                         ("float64 brute force" if bits == 0 else "TOR_ACCEL_BLOCKS|TOR_ACCEL_F32 = tor_render()'s default")}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds)
-    elif rank == 0:
-        result["cpu_baseline"] = ({"value": None, "note": "timed at N = 1 only (python bench.py): the ranks of a multi-GPU run keep the host cores busy"}
-                                  if world > 1 else None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.no_pmc:
+        # HBM traffic of ONE launch of this run's kernel -- rank 0's shard -- now that the job is over and GPU 0 is free
+        traffic, traffic_note = live_traffic(W, H, spp, args.depth, seeding, arith, accel, shard=(0, world, args.row_tile))
+        result["roofline"]["traffic"] = traffic["bytes"] if traffic else None
+        result["roofline"]["traffic_detail"] = traffic if traffic else traffic_note
+        result["roofline"]["traffic_scope"] = f"one launch = rank 0's shard ({len(my_rows)} of {H} rows)"
     if rank == 0:
+        # (N > 1: after the process group is gone -- the other ranks have left, the host cores are free again)
+        result["cpu_baseline"] = (cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds) if not args.no_cpu_baseline
+                                  else {"value": None, "note": "skipped (--no-cpu-baseline)"})
         print(json.dumps(result), flush=True)
 
 

@@ -128,7 +128,10 @@ enum {
 /* How the row shards of a multi-device tor_render_opt() reach the caller's canvas. */
 enum {
   TOR_GATHER_AUTO = 0,  /* RCCL when the devices are distinct, librccl loads and the communicator passes its
-                           self-check; if that leg fails: peer copies; if those fail: HOST (tor_last_note)   */
+                           self-check; if that leg fails -- or does not COMPLETE: every wait of the RCCL leg has a
+                           deadline (TOR_RCCL_TIMEOUT_MS per transfer, default 10 s + 1 ms / MB; TOR_RCCL_INIT_TIMEOUT_MS
+                           for communicator creation + self-check, default 120 s), past it the communicators are
+                           aborted -- peer copies; if those fail: HOST (tor_last_note)                           */
   TOR_GATHER_RCCL = 1,  /* single-process RCCL (ncclCommInitAll): every device sends its shard to
                            devices[0] over xGMI, one de-interleave kernel, one D2H (BASELINE north_star) */
   TOR_GATHER_PEER = 2,  /* the same with hipMemcpyPeerAsync instead of RCCL                              */
@@ -159,11 +162,15 @@ typedef struct TorOptions {
   int32_t gather;       /* TOR_GATHER_* */
   int32_t devices[TOR_MAX_DEVICES];
   /* TOR_SEED_PIXEL only: which kernel walks the pixel chains (same canvas either way).
-   * TOR_PIXEL_KERNEL_AUTO: frames of 16 K .. 625 K pixels (per device) with both exact accelerations and >= 32 spp
-   * are SHARED -- the tiles that carry the largest part of a probed cost go to the one-wave-per-pixel kernel on a
-   * second stream, the one-lane-per-pixel kernel renders the rest at the same time (TOR_SPLIT_FRAC overrides the
-   * fraction, 0 = off); otherwise one wave per pixel up to 114688 pixels (TOR_COOP_MAX_PIXELS), one lane per pixel
-   * above.  LANE / WAVE force one kernel for the whole frame (WAVE falls back to LANE when the scene does not fit LDS). */
+   * TOR_PIXEL_KERNEL_AUTO: with both exact accelerations, >= 32 spp and a single-level culling layout (<= 128 block
+   * boxes) every frame size runs the one-lane-per-pixel kernel with the CHAIN HAND-OFF -- lanes push their long pixel
+   * chains to server waves inside the same launch (the launch covers the whole GPU and assumes exclusive
+   * use of it: tor_context_handoff_stalled; TOR_MIGRATE=0 turns it off).  Where the hand-off cannot run: frames of
+   * 16 K pixels and more (per device) with both accelerations and >= 32 spp are SHARED -- the tiles that carry the
+   * largest part of a probed cost go to the one-wave-per-pixel kernel on a second stream, the lane kernel renders the
+   * rest at the same time (TOR_SPLIT_FRAC overrides the fraction, 0 = off); otherwise one wave per pixel up to 114688
+   * pixels (TOR_COOP_MAX_PIXELS), one lane per pixel above.  LANE / WAVE force one kernel for the whole frame, without
+   * hand-off (WAVE falls back to LANE when the scene does not fit LDS). */
   int32_t pixel_kernel;
 } TorOptions;
 
@@ -194,6 +201,10 @@ enum {
  *   TOR_SCREEN = 0            (float64 brute force only) every ray x object through the reference's unfused discriminant;
  *                             unset: the object loop is a conservative FMA screen of the same quadratic and only its
  *                             candidates see the unfused operations -- same canvas (csrc/tor_screen.hpp), read at context creation
+ *   TOR_DEFAULT_SEEDING = pixel | sample   the ONE knob here that selects a different (equally valid) image: `pixel`
+ *                             (default) = the reference's streams, one per pixel (render.nim:59-67); `sample` = the
+ *                             counter-based per-sample streams of TOR_SEED_SAMPLE -- what lets 8 GPUs share a 1080p frame
+ *                             (a pixel stream is a sequential chain) and the mode the headline Msamples/s is quoted on
  *   TOR_DEVICES = "all" | "0,1,2,3"   render on several GPUs (TorOptions.device_count / devices)
  *   TOR_GATHER  = rccl | peer | host  (TorOptions.gather)
  * The device scene is cached: a call whose object list is byte-identical to the previous call's (on that
@@ -224,6 +235,14 @@ TOR_API const char* tor_last_error(void);
  * gather ran ("gather: rccl" | "gather: peer" | "gather: host"), preceded by the legs TOR_GATHER_AUTO tried first and
  * why they failed -- AUTO walks RCCL -> peer copies -> per-device D2H and never returns a wrong canvas.  Not an error. */
 TOR_API const char* tor_last_note(void);
+
+/* Facts about the last successful multi-device tor_render / tor_render_opt on this thread (what a scaling log needs):
+ * out[0] = the TOR_GATHER_* leg that assembled the frame, out[1] = ranks of the RCCL communicator that carried it
+ * (ncclCommCount; 0 when the leg was not RCCL), out[2] = entries of the device list, out[3] = 1 when they were distinct GPUs. */
+TOR_API int tor_last_gather_info(int32_t out[4]);
+/* Duration of the dominant kernel (integrate_kernel) on every device of that call, in milliseconds: HIP events around the
+ * launch on the launch's own stream.  Writes min(cap, n) values, returns n = entries of the device list. */
+TOR_API int32_t tor_last_device_kernel_ms(float* out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------ */
 /* Resident-context API (frame loops: trace_of_radiance_animation.nim:173-196; benchmarks; */
@@ -265,9 +284,24 @@ TOR_API int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nro
 TOR_API int tor_comm_unique_id(uint8_t id_out[128]);
 TOR_API int tor_comm_init_rank(TorContext* ctx, const uint8_t id[128], int32_t rank, int32_t world);
 TOR_API int tor_comm_destroy(TorContext* ctx);
+/* ncclCommAbort: for a host whose watchdog saw a gather that does not complete (bench.py polls its stream with a deadline);
+ * RCCL's kernels leave, the context has no communicator afterwards.  tor_comm_count: ranks of the communicator
+ * (ncclCommCount), 0 without one. */
+TOR_API int tor_comm_abort(TorContext* ctx);
+TOR_API int tor_comm_count(TorContext* ctx, int32_t* ranks_out);
 TOR_API int tor_render_gather_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols,
                                      int32_t samples_per_pixel, float gamma_correction, int64_t max_depth,
                                      const TorOptions* opt, int32_t root, double* d_frame, void* hip_stream);
+
+/* Chain hand-off of the last launch of `ctx` (TOR_SEED_PIXEL with both exact accelerations): the launch covers
+ * the whole GPU and its waves wait for each other, so it assumes exclusive use of the device's compute units (hand-off
+ * launches of ONE process are chained per device by the library; TOR_MIGRATE=0 turns the hand-off off).  If some of its
+ * workgroups never become resident (another process's persistent kernel, a CU mask) the waiting waves give up after
+ * TOR_SRV_STALL_S seconds without progress (default 60, 0 = never) and the frame is INCOMPLETE: tor_render / tor_render_opt /
+ * tor_render_frame_h264 notice and render the frame again without the hand-off; a caller of the asynchronous
+ * tor_render_device asks here.  Blocks until the last launch's stream is idle.  *stalled_out = 1: render again with
+ * TOR_PIXEL_KERNEL_LANE.  total_out (nullable): frames the blocking entry points re-rendered so far. */
+TOR_API int tor_context_handoff_stalled(TorContext* ctx, int32_t* stalled_out, int64_t* total_out);
 
 /* Scene-cache counters of a context: out[0] = tor_scene_upload calls, out[1] = calls that found the device
  * scene up to date (nothing rebuilt, nothing copied), out[2] = device layouts built so far. */

@@ -106,12 +106,13 @@ def test_bad_settings_say_why_before_a_device_is_touched(tor, monkeypatch):
     scene, cam = tor.random_scene(0xFACADE), tor.camera()
     cv = tor.new_canvas(4, 4, 1, 2.2)
     cv.pixels[:] = 7.0
-    for kw, word in ((dict(devices=[0, 0], shard_index=1, shard_count=2), "device list"), (dict(devices=[0, 1], device=0), "device"),
+    for kw, word in ((dict(devices=[0, 0], shard_index=1, shard_count=2), "device list"), (dict(devices=[0, 1], device=5), "device"),
                      (dict(row_tile=-3), "row_tile"), (dict(accel=9), "accel"), (dict(seeding=5), "seeding")):
         with pytest.raises(tor.TorError) as e:
             tor.render(cv, cam, scene.list(), 5, tor.make_options(**kw))
         assert e.value.code == -1 and word in str(e.value), (kw, str(e.value))
-    for name, val in (("TOR_GATHER", "carrier-pigeon"), ("TOR_DEFAULT_ACCEL", "7"), ("TOR_DEFAULT_ACCEL", "x"), ("TOR_DEVICES", "0,abc")):
+    for name, val in (("TOR_GATHER", "carrier-pigeon"), ("TOR_DEFAULT_ACCEL", "7"), ("TOR_DEFAULT_ACCEL", "x"), ("TOR_DEVICES", "0,abc"),
+                      ("TOR_DEFAULT_SEEDING", "per-photon")):
         monkeypatch.setenv(name, val)
         with pytest.raises(tor.TorError) as e:
             tor.render(cv, cam, scene.list(), 5)            # tor_render(): the settings come from the environment

@@ -149,7 +149,7 @@ def test_gather_fallback_chain_under_fault_injection(tor):
 def test_option_validation_says_why(tor):
     scene, cam = tor.random_scene(0xFACADE), tor.camera()
     cv = tor.new_canvas(8, 8, 1)
-    for kw, word in ((dict(devices=[0, 0], shard_index=1, shard_count=2), "device list"), (dict(devices=[0, 0], device=0), "device"),
+    for kw, word in ((dict(devices=[0, 0], shard_index=1, shard_count=2), "device list"), (dict(devices=[0, 0], device=3), "device"),
                      (dict(row_tile=-3), "row_tile"), (dict(accel=9), "accel")):
         with pytest.raises(tor.TorError) as e:
             tor.render(cv, cam, scene.list(), 5, tor.make_options(**kw))

@@ -132,6 +132,7 @@ EXPORTED_SYMBOLS = [
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
     "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
+    "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
 ]
 
 _lib = None
@@ -249,6 +250,12 @@ def lib():
     L.tor_render_gather_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int64,
                                            C.POINTER(Options), C.c_int32, C.c_void_p, C.c_void_p]
     L.tor_context_scene_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.tor_last_gather_info.argtypes = [C.POINTER(C.c_int32)]
+    L.tor_last_device_kernel_ms.argtypes = [C.POINTER(C.c_float), C.c_int32]
+    L.tor_last_device_kernel_ms.restype = C.c_int32
+    L.tor_comm_abort.argtypes = [C.c_void_p]
+    L.tor_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.tor_context_handoff_stalled.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -448,6 +455,22 @@ def last_note() -> str:
     return lib().tor_last_note().decode("utf-8", "replace")
 
 
+def last_gather_info() -> dict:
+    """Facts about this thread's last multi-device render(): the gather leg, the RCCL communicator's rank count (0: not
+    RCCL), entries of the device list, whether they were distinct GPUs (tor_last_gather_info)."""
+    out = (C.c_int32 * 4)()
+    _check(lib().tor_last_gather_info(out))
+    return {"leg": {GATHER_RCCL: "rccl", GATHER_PEER: "peer", GATHER_HOST: "host"}.get(int(out[0]), "none"),
+            "rccl_ranks": int(out[1]), "devices": int(out[2]), "distinct_devices": bool(out[3])}
+
+
+def last_device_kernel_ms() -> list:
+    """integrate_kernel's duration on every device of this thread's last multi-device render() (HIP events on each launch stream)."""
+    buf = (C.c_float * 64)()
+    n = int(lib().tor_last_device_kernel_ms(buf, 64))
+    return [float(buf[k]) for k in range(min(n, 64))]
+
+
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * 128)()
     _check(lib().tor_comm_unique_id(buf))
@@ -564,6 +587,23 @@ class Context:
 
     def comm_destroy(self):
         _check(lib().tor_comm_destroy(self._h))
+
+    def comm_abort(self):
+        """ncclCommAbort (a gather that does not complete: RCCL's kernels leave)."""
+        _check(lib().tor_comm_abort(self._h))
+
+    def comm_count(self) -> int:
+        """Ranks of the context's RCCL communicator (ncclCommCount); 0 without one."""
+        n = C.c_int32(0)
+        _check(lib().tor_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def handoff_stalled(self):
+        """(stalled, frames re-rendered so far) of the last launch's chain hand-off (tor_context_handoff_stalled); blocks."""
+        st = C.c_int32(0)
+        tot = C.c_int64(0)
+        _check(lib().tor_context_handoff_stalled(self._h, C.byref(st), C.byref(tot)))
+        return bool(st.value), int(tot.value)
 
     def render_gather_device(self, cam: Camera, nrows: int, ncols: int, spp: int, gamma: float, max_depth: int,
                              options: Options, root: int, d_frame_ptr: int, stream_ptr: int = 0):

@@ -35,6 +35,8 @@ static_assert(sizeof(tor::Camera) == sizeof(TorCamera), "device camera mirrors T
 static_assert(offsetof(TorOptions, device_count) == 32, "the round-1 TorOptions is a prefix of the current one");
 
 namespace {
+std::mutex g_handoff_mutex;                    // hand-off launches are chained per device (tor_render_device)
+std::map<int, hipEvent_t> g_handoff_event;     // device -> end of the last hand-off launch of this process
 thread_local std::string g_last_error = "";
 thread_local double g_last_timing[5] = {0, 0, 0, 0, 0};
 }  // namespace
@@ -142,6 +144,16 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
       if (endp != e && *endp == 0 && v >= 0 && v <= (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) o.accel = (int32_t)v;
       else return no("TOR_DEFAULT_ACCEL must be 0, 1, 2 or 3");
     }
+    // TOR_DEFAULT_SEEDING = pixel | sample: which random streams the drop-in uses.  `pixel` (default) is the reference's
+    // render.nim:59-67 -- one stream per pixel, the spp samples in sequence.  `sample` is the counter-based stream of
+    // BASELINE.json's north_star, seed(row, col, sample): render.nim:59-60 re-seeds per pixel "to be able to parallelize the
+    // outer loops"; this is the same idea one level down, and it is what lets 8 GPUs share a 1080p frame.  It is
+    // the one knob of this list that changes pixels (a different, equally valid sample set; oracle mode SAMPLE / QUANTIZED).
+    if (const char* e = std::getenv("TOR_DEFAULT_SEEDING")) {
+      if (!std::strcmp(e, "sample")) o.seeding = TOR_SEED_SAMPLE;
+      else if (!std::strcmp(e, "pixel")) o.seeding = TOR_SEED_PIXEL;
+      else return no("TOR_DEFAULT_SEEDING must be pixel or sample");
+    }
     if (const char* e = std::getenv("TOR_DEVICES")) {
       TorOptions t = o;
       if (parse_device_list(e, t)) o = t;
@@ -168,7 +180,14 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
   if (o.device_count > 1) {
     // the device list IS the sharding and the placement: shard_index / shard_count / device stay at their defaults (tor_render.h)
     if (o.shard_count != 1 || o.shard_index != 0) return no("with a device list, shard_index / shard_count must be left at 0 / 1: entry k renders shard k");
-    if (o.device != -1) return no("with a device list, `device` must be left at -1");
+    // (`device` is ignored with a device list -- a zero-initialised TorOptions says 0 there, as it says 0 for shard_count and
+    // row_tile, which are tolerated too; only a value that names a device OUTSIDE the list is a contradiction: ADVICE r3)
+    if (o.device > 0) {
+      bool listed = false;
+      for (int k = 0; k < o.device_count; ++k) listed = listed || o.devices[k] == o.device;
+      if (!listed) return no("with a device list, `device` must be -1, 0 or one of the listed ordinals (it is ignored)");
+    }
+    o.device = -1;
     for (int k = 0; k < o.device_count; ++k)
       if (o.devices[k] < 0) return no("negative ordinal in the device list");
   } else if (o.device_count == 1) {
@@ -460,6 +479,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   const long long n_values = npix * 3;
   ctx->timing_valid = false;
   ctx->last_samples = 0;
+  ctx->last_migrate = false;
   if (npix == 0) return TOR_OK;
 
   // a ring slot (events, camera, bounds, counters, tile schedule) is reused every kRing launches: its previous
@@ -502,53 +522,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       split_frac = 20000.0f / (float)npix;
       if (split_frac > 0.2f) split_frac = 0.2f;
       if (split_frac < 0.02f) split_frac = 0.02f;
-    }
-  }
-  // Chain hand-off (DESIGN 4.10): the lane kernel pushes its long chains to server waves inside the same launch -- it
-  // replaces both the whole-frame wave kernel and split mode wherever the launch's kernel variant carries the servers
-  // (both exact accelerations, single-level culling layout with float32 records, <= 128 block boxes) and the probe runs.
-  bool mig_candidate = false;
-  if (o.seeding == TOR_SEED_PIXEL && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->mig_mode != 0 && o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) &&
-      ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && npix > tor::kTilePixelsHost && !ctx->collect_stats && ctx->n_objects > 0) {
-    const int rc = tor::ensure_layouts(ctx, o.accel);
-    if (rc != TOR_OK) return rc;
-    const tor::HostAccel& ha = ctx->accel[1];
-    mig_candidate = ctx->accel_built[1] && ha.available && ha.sp32 && !ha.two_level && (ha.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad <= 128;
-  }
-  const bool split_applies = !mig_candidate && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
-                             npix >= ctx->split_min_pixels && npix <= ctx->split_max_pixels && !ctx->collect_stats && ctx->n_objects > 0;
-  const bool want_wave_kernel = o.pixel_kernel == TOR_PIXEL_KERNEL_WAVE ||
-                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels && !split_applies && !mig_candidate);
-  if (o.seeding == TOR_SEED_PIXEL && !ctx->collect_stats && want_wave_kernel && ctx->n_objects > 0) {
-    const int rc = tor::ensure_layouts(ctx, 0);
-    if (rc != TOR_OK) return rc;
-    const tor::DeviceLayout& L = ctx->flat[0];
-    p.cold = L.cold;
-    p.n_cold_slots = L.n_sorted;
-    p.coop_slots = (L.n_sorted + 63) / 64 * 64;
-    p.coop_trips = L.coop_trips;
-    const int bpc = tor::coop_blocks_per_cu(p, o.arith);
-    if (bpc > 0) {
-      p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
-      p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
-      p.n_pixels = (unsigned)npix;
-      p.work_counter = slot_counters;
-      p.out = d_pixels;
-      ctx->cam_host[slot] = *cam;
-      p.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
-      HIP_TRY(hipMemcpyAsync((void*)p.cam_dev, &ctx->cam_host[slot], sizeof(TorCamera), hipMemcpyHostToDevice, stream));
-      long long blocks = (npix + (tor::kThreads / 64) - 1) / (tor::kThreads / 64);
-      const long long resident = (long long)ctx->num_cus * bpc;
-      if (blocks > resident) blocks = resident;
-      HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
-      HIP_TRY(tor::launch_coop(p, o.arith, (int)blocks, stream));
-      HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
-      ctx->launches += 1;
-      ctx->last_slot = slot;
-      ctx->timing_valid = true;
-      ctx->last_samples = (int64_t)npix * spp;
-      HIP_TRY(tor::launch_finalize(d_pixels, n_values, 1.0 / (double)spp, 1.0 / (double)gamma_correction, stream));
-      return TOR_OK;
     }
   }
   // Layout configuration of a launch: which device arrays the kernel walks for `accel`, the per-call block bounds and the
@@ -658,24 +631,88 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     }
     return TOR_OK;
   };
+  // Launch configuration, shared by the hand-off decision below and the launch itself.
   bool use_accel = false;
   int stage_wg = 0;  // > 0: compact records staged in LDS, at most this many workgroups per CU
   const tor::HostAccel* hacc_p = nullptr;
-  {
+  bool configured = false;
+  // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
+  // kernel variant's register budget follows it
+  int cap = 0, waves_per_simd = 0;
+  long long resident_waves = 0;
+  auto configure_frame = [&]() -> int {
+    if (configured) return TOR_OK;
     const int rc = configure(p, o.accel, ctx->bnd_host[slot], ctx->bnd32_host[slot], use_accel, stage_wg, hacc_p);
+    if (rc != TOR_OK) return rc;
+    cap = ctx->max_blocks_per_cu[o.seeding][o.accel != 0];
+    if (cap < 1) cap = 4;
+    if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
+    waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
+    int bpc_eff = tor::integrate_blocks_per_cu(p, o.seeding, o.arith, waves_per_simd);
+    if (bpc_eff > cap) bpc_eff = cap;
+    resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
+    configured = true;
+    return TOR_OK;
+  };
+  const long long n_tiles = (npix + tor::kTilePixelsHost - 1) / tor::kTilePixelsHost;
+  // Chain hand-off (DESIGN 4.10): the lane kernel pushes its long chains to server waves inside the same launch -- it
+  // replaces both the whole-frame wave kernel and split mode wherever the launch's kernel variant carries the servers
+  // (both exact accelerations, single-level culling layout with float32 records, <= 128 block boxes) and the probe runs.
+  // Decided HERE, in full, before split mode and the wave-per-pixel kernel are ruled out: a frame whose hand-off cannot
+  // run after all (non-finite shutter range -> no culling, a variant without servers, a tiny machine) keeps those two
+  // (ADVICE r3).
+  bool migrate = false;
+  if (o.seeding == TOR_SEED_PIXEL && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->mig_mode != 0 && o.accel == (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) &&
+      ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp && npix > tor::kTilePixelsHost && !ctx->collect_stats && ctx->n_objects > 0) {
+    const int rc = configure_frame();
+    if (rc != TOR_OK) return rc;
+    const tor::HostAccel& ha = ctx->accel[1];
+    migrate = ctx->accel_built[1] && ha.available && ha.sp32 && !ha.two_level && (ha.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad <= 128 &&
+              use_accel && n_tiles > 1 && tor::integrate_variant_serves_chains(p, o.seeding) && resident_waves >= 8;
+  }
+  const bool split_applies = !migrate && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
+                             npix >= ctx->split_min_pixels && npix <= ctx->split_max_pixels && !ctx->collect_stats && ctx->n_objects > 0;
+  const bool want_wave_kernel = o.pixel_kernel == TOR_PIXEL_KERNEL_WAVE ||
+                                (o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && ctx->coop_max_pixels > 0 && npix <= ctx->coop_max_pixels && !split_applies && !migrate);
+  if (o.seeding == TOR_SEED_PIXEL && !ctx->collect_stats && want_wave_kernel && ctx->n_objects > 0) {
+    const int rc = tor::ensure_layouts(ctx, 0);
+    if (rc != TOR_OK) return rc;
+    const tor::DeviceLayout& L = ctx->flat[0];
+    tor::KParams wp{};
+    wp.cold = L.cold;
+    wp.n_cold_slots = L.n_sorted;
+    wp.coop_slots = (L.n_sorted + 63) / 64 * 64;
+    wp.coop_trips = L.coop_trips;
+    const int bpc = tor::coop_blocks_per_cu(wp, o.arith);
+    if (bpc > 0) {
+      wp.nrows = nrows; wp.ncols = ncols; wp.spp = spp; wp.max_depth = (int)max_depth;
+      wp.shard_index = o.shard_index; wp.shard_count = o.shard_count; wp.row_tile = o.row_tile;
+      wp.n_pixels = (unsigned)npix;
+      wp.work_counter = slot_counters;
+      wp.out = d_pixels;
+      ctx->cam_host[slot] = *cam;
+      wp.cam_dev = (const double*)((char*)ctx->cam_ring.ptr + (size_t)slot * sizeof(TorCamera));
+      HIP_TRY(hipMemcpyAsync((void*)wp.cam_dev, &ctx->cam_host[slot], sizeof(TorCamera), hipMemcpyHostToDevice, stream));
+      long long blocks = (npix + (tor::kThreads / 64) - 1) / (tor::kThreads / 64);
+      const long long resident = (long long)ctx->num_cus * bpc;
+      if (blocks > resident) blocks = resident;
+      HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+      HIP_TRY(tor::launch_coop(wp, o.arith, (int)blocks, stream));
+      HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+      ctx->launches += 1;
+      ctx->last_slot = slot;
+      ctx->timing_valid = true;
+      ctx->last_samples = (int64_t)npix * spp;
+      HIP_TRY(tor::launch_finalize(d_pixels, n_values, 1.0 / (double)spp, 1.0 / (double)gamma_correction, stream));
+      return TOR_OK;
+    }
+  }
+  {
+    const int rc = configure_frame();
     if (rc != TOR_OK) return rc;
   }
   const tor::HostAccel& hacc = *hacc_p;
   std::vector<double>& bnd_host = ctx->bnd_host[slot];
-  // launch shape: workgroups per CU for this mode (fewer when the LDS staging needs the room); the
-  // kernel variant's register budget follows it
-  int cap = ctx->max_blocks_per_cu[o.seeding][o.accel != 0];
-  if (cap < 1) cap = 4;
-  if (stage_wg > 0 && stage_wg < cap) cap = stage_wg;
-  const int waves_per_simd = ctx->waves_override > 0 ? ctx->waves_override : ((cap >= 2 && cap <= 4) ? cap : 4);
-  int bpc_eff = tor::integrate_blocks_per_cu(p, o.seeding, o.arith, waves_per_simd);
-  if (bpc_eff > cap) bpc_eff = cap;
-  const long long resident_waves = (long long)ctx->num_cus * bpc_eff * (tor::kThreads / 64);
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
   p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
   p.work_counter = slot_counters;
@@ -688,7 +725,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.pixel_cost = nullptr;
   ctx->last_probe_pixels = 0;
   p.sched = nullptr;
-  const long long n_tiles = (npix + tor::kTilePixelsHost - 1) / tor::kTilePixelsHost;
   if (o.seeding == TOR_SEED_PIXEL) {
     p.total_work = (unsigned long long)n_tiles * tor::kTilePixelsHost;  // tiles of 64 pixels
     p.chunk = tor::kTilePixelsHost;
@@ -709,7 +745,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   p.screen = ctx->screen ? 1 : 0;
   p.n_boxes = use_accel ? (int)((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) : 0;
   p.mig = nullptr;
-  const bool migrate = mig_candidate && use_accel && n_tiles > 1 && tor::integrate_variant_serves_chains(p, o.seeding) && resident_waves >= 8;
   if (migrate) blocks = (int)(resident_waves / (tor::kThreads / 64));  // the whole machine: waves without a tile are servers at once
   p.n_waves = (unsigned)(blocks * (tor::kThreads / 64));
   p.wave_log = nullptr;
@@ -821,6 +856,10 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       p.mig_flags = ctx->mig_flags;
       p.mig_patience = (unsigned)(ctx->srv_patience_us > 0 ? ctx->srv_patience_us : 0) * 100u;
       p.mig_tail_rest = ctx->mig_tail_rest;
+      // (read per launch, not per context: the drop-in's cached contexts outlive any one caller's settings)
+      double stall_s = ctx->mig_stall_s;
+      if (const char* c = std::getenv("TOR_SRV_STALL_S")) stall_s = std::atof(c);
+      p.mig_stall_ticks = stall_s > 0.0 ? (unsigned long long)(stall_s * 1e8) + 2ull : (stall_s < 0.0 ? 1ull : 0ull);  // (< 0, a test setting: every waiting server gives up at its first look)
       ms.mig = p.mig;
       ms.lavg_scale = (float)spp / (float)ctx->probe_spp / ((float)blocks * (float)tor::kThreads);
       ms.srv_frac = ctx->srv_frac;
@@ -862,9 +901,26 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       return TOR_OK;
     }
   }
-  HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
-  HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));
-  HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+  ctx->last_migrate = migrate && p.mig != nullptr;
+  if (ctx->last_migrate) {
+    // A hand-off launch covers the whole machine and its waves WAIT for each other (servers for lane waves): two of them
+    // interleaved on one GPU -- two contexts on one device, e.g. a device list that repeats an ordinal -- would each hold part
+    // of the machine and wait for workgroups that can never start.  So hand-off launches of this process are chained per
+    // device: each waits (on the device, not the host) for the previous one's end event.  Kernels without
+    // inter-workgroup waits may still overlap it; they end on their own.
+    std::lock_guard<std::mutex> lock(g_handoff_mutex);
+    hipEvent_t& ev = g_handoff_event[ctx->device];
+    if (ev) HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+    else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+    HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));
+    HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+    HIP_TRY(hipEventRecord(ev, stream));
+  } else {
+    HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+    HIP_TRY(tor::launch_integrate(p, o.seeding, o.arith, waves_per_simd, blocks, stream));
+    HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+  }
   ctx->launches += 1;
   ctx->last_slot = slot;
   ctx->timing_valid = true;
@@ -969,6 +1025,8 @@ int tor_render_frame_h264(TorContext* ctx, const TorCamera* cam, int32_t nrows, 
   HIP_TRY(ctx->slice.ensure((size_t)n));
   int rc = tor_render_device(ctx, cam, nrows, ncols, spp, gamma_correction, max_depth, opt, (double*)ctx->scratch.ptr, nullptr);
   if (rc != TOR_OK) return rc;
+  rc = tor::rerender_if_stalled(ctx, cam, nrows, ncols, spp, gamma_correction, max_depth, opt, (double*)ctx->scratch.ptr, nullptr);
+  if (rc != TOR_OK) return rc;
   rc = tor_encode_frame_device(ctx, (const double*)ctx->scratch.ptr, nrows, ncols, (uint8_t*)ctx->slice.ptr, nullptr, nullptr,
                                nullptr, nullptr);
   if (rc != TOR_OK) return rc;
@@ -1050,6 +1108,16 @@ int tor_last_handoff_counters(TorContext* ctx, uint64_t out[16]) {
   return TOR_OK;
 }
 
+int tor_context_handoff_stalled(TorContext* ctx, int32_t* stalled_out, int64_t* total_out) {
+  if (!ctx || !stalled_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_context_handoff_stalled: NULL argument");
+  bool st = false;
+  const int rc = tor::handoff_stalled(ctx, (hipStream_t)ctx->last_stream, &st);
+  if (rc != TOR_OK) return rc;
+  *stalled_out = st ? 1 : 0;
+  if (total_out) *total_out = ctx->n_stalled_frames;
+  return TOR_OK;
+}
+
 int tor_last_stats(TorContext* ctx, TorStats* out) {
   if (!ctx || !out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: NULL argument");
   if (!ctx->collect_stats) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: stats not enabled");
@@ -1074,6 +1142,32 @@ static std::map<std::pair<int, int>, TorContext*> g_default_ctx;  // cached cont
 }  // extern "C"
 
 namespace tor {
+// After a hand-off launch (ctx->last_migrate): waits for the stream and reads the launch's kMigStalled word.
+int handoff_stalled(TorContext* ctx, hipStream_t stream, bool* stalled) {
+  *stalled = false;
+  if (!ctx->last_migrate) return TOR_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(stream));
+  unsigned long long w = 0;
+  HIP_TRY(hipMemcpy(&w, (unsigned long long*)ctx->counters.ptr + (size_t)ctx->last_slot * TorContext::kSlotWords + TorContext::kMigWord0 + tor::kMigStalled,
+                    sizeof w, hipMemcpyDeviceToHost));
+  *stalled = w != 0;
+  return TOR_OK;
+}
+
+int rerender_if_stalled(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols, int32_t spp, float gamma_correction,
+                        int64_t max_depth, const TorOptions* o, double* d_pixels, hipStream_t stream) {
+  bool stalled = false;
+  int rc = handoff_stalled(ctx, stream, &stalled);
+  if (rc != TOR_OK || !stalled) return rc;
+  ctx->n_stalled_frames += 1;
+  const int saved = ctx->mig_mode;
+  ctx->mig_mode = 0;
+  rc = tor_render_device(ctx, cam, nrows, ncols, spp, gamma_correction, max_depth, o, d_pixels, stream);
+  ctx->mig_mode = saved;
+  return rc;
+}
+
 int default_context(int device, int replica, TorContext** out) {
   std::lock_guard<std::mutex> lock(g_ctx_mutex);
   TorContext*& ctx = g_default_ctx[{device, replica}];
@@ -1147,6 +1241,11 @@ int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableList worl
   HIP_TRY(hipEventRecord(ctx->ev_call[0], ctx->stream));
   rc = tor_render_device(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction,
                          max_depth, &o, (double*)ctx->scratch.ptr, ctx->stream);
+  if (rc != TOR_OK) return rc;
+  // (a hand-off launch whose servers gave up -- not all of its workgroups were resident -- left the frame incomplete: render it
+  // again without the hand-off before anything reaches the caller's canvas)
+  rc = tor::rerender_if_stalled(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction, max_depth, &o,
+                                (double*)ctx->scratch.ptr, ctx->stream);
   if (rc != TOR_OK) return rc;
   HIP_TRY(hipEventRecord(ctx->ev_call[1], ctx->stream));
   rc = tor::download_rows(ctx, ctx->scratch.ptr, local_rows, row_bytes, o.shard_count > 1 ? rows.data() : nullptr,

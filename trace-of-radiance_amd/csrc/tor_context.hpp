@@ -188,6 +188,12 @@ struct TorContext {
   int mig_tail_rest = 256;   // TOR_TAIL_REST
   unsigned mig_flags = (8u << 8) | 2u | 4u;  // TOR_MIG_FLAGS (tor_kernels.hpp KParams::mig_flags)
   tor::DeviceBuffer mig_rec, mig_flag;
+  // A waiting server that sees no progress of the frame for this long flags the frame as incomplete and leaves
+  // (KParams::mig_stall_ticks; TOR_SRV_STALL_S, 0 = never): the launch assumes all of its workgroups resident, and this is
+  // the way out when they are not.  The host-canvas entry points then render the frame again without the hand-off.
+  double mig_stall_s = 60.0;
+  int64_t n_stalled_frames = 0;  // frames the host-canvas entry points rendered again because the hand-off stalled
+  bool last_migrate = false;  // the last launch carried the hand-off (its kMigStalled word means something)
 };
 
 namespace tor {
@@ -205,6 +211,12 @@ int ensure_layouts(TorContext* ctx, int accel);
 // context's pinned staging, worker threads move the chunks on while later chunks are still in flight.  Blocking.
 int download_rows(TorContext* ctx, const void* d_src, int64_t n_rows, size_t row_bytes, const int32_t* rows,
                   char* dst, hipStream_t stream);
+
+// Hand-off launches (ctx->last_migrate): handoff_stalled waits for `stream` and reads the launch's kMigStalled word;
+// rerender_if_stalled renders the frame again with the hand-off off when it is set (same arguments as tor_render_device).
+int handoff_stalled(TorContext* ctx, hipStream_t stream, bool* stalled);
+int rerender_if_stalled(TorContext* ctx, const TorCamera* cam, int32_t nrows, int32_t ncols, int32_t spp, float gamma_correction,
+                        int64_t max_depth, const TorOptions* o, double* d_pixels, hipStream_t stream);
 
 // default (cached) context of the host-canvas entry points: one per (device, replica)
 int default_context(int device, int replica, TorContext** out);

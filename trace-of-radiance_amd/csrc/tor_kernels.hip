@@ -2000,6 +2000,11 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
     // frame the lanes that still ran lost theirs every few hundred ns -- measured 25x slower; a compare-and-swap claim
     // (instead of tickets) made every waiter hammer one line whenever a chain was pending: the same.
     unsigned polls = 0, naps = 1;
+    // (stall escape, ADVICE r3: the launch assumes that all of its workgroups are resident -- servers wait for lane waves.  If
+    // some never start (another process's persistent kernel, a CU mask), the resident ones would wait for ever and the host with
+    // them.  A waiting server therefore watches the frame's progress words; when none of them has moved for mig_stall_ticks it
+    // flags the frame as incomplete and leaves -- its ticket stays a hole, which is why the host must re-render: tor_api.cpp)
+    unsigned long long stall_t0 = wall_clock64(), stall_sig = ~0ull;
     for (;;) {
       unsigned ready = 0;
       if (lane == 0 && tk < cap) {
@@ -2017,6 +2022,24 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
           tail = bcast_first_u64(tail);
           if (tail > cap) tail = cap;
           if (tk >= tail) { quit = true; break; }
+        }
+        if (p.mig_stall_ticks != 0 && (polls & 15u) == 15u) {
+          unsigned long long sig = 0;
+          if (lane == 0) {
+            sig = __hip_atomic_load(p.work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                  __hip_atomic_load(p.mig + kMigTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                  __hip_atomic_load(p.mig + kMigServed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                  (__hip_atomic_load(p.mig + kMigLaneWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 40);
+          }
+          sig = bcast_first_u64(sig);
+          const unsigned long long now = wall_clock64();
+          // (mig_stall_ticks == 1, a test setting: the first look counts as a stall)
+          if (sig != stall_sig && p.mig_stall_ticks != 1ull) { stall_sig = sig; stall_t0 = now; }
+          else if (now - stall_t0 > p.mig_stall_ticks || p.mig_stall_ticks == 1ull) {
+            if (lane == 0) __hip_atomic_store(p.mig + kMigStalled, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            quit = true;
+            break;
+          }
         }
       }
       polls += 1;
@@ -2560,6 +2583,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const double* gathered
   frame[i] = gathered[(long long)shard * shard_stride + (long long)local_row * row_values + within_row];
 }
 
+// keeps its stream busy until the host sets *flag (or max_ticks pass): the stand-in for a collective that never completes
+__global__ void spin_until_kernel(volatile unsigned* flag, unsigned long long max_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (*flag == 0u && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
+}
+
 __global__ void selftest_kernel(int op, const double* x, const double* y, double* out0, double* out1,
                                 long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2700,6 +2729,11 @@ hipError_t launch_gather_rows(const double* gathered, double* frame, int nrows, 
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gathered, frame, nrows, ncols,
                      row_tile, shard_count, shard_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_spin_until(volatile unsigned* flag, unsigned long long max_ticks, hipStream_t stream) {
+  hipLaunchKernelGGL(spin_until_kernel, dim3(1), dim3(64), 0, stream, flag, max_ticks);
   return hipGetLastError();
 }
 

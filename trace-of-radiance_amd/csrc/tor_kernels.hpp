@@ -88,6 +88,7 @@ struct KParams {
   int mig_tail_lanes;           // a wave that has run out of fresh pixels hands its chains over from this many live lanes down
   int mig_tail_rest;            // ... with more live lanes than that: only chains with at least this many bounce iterations to go, and only to idle servers
   unsigned mig_patience;        // 100 MHz ticks a dedicated server waits without a chain before it turns into a lane wave (0: never)
+  unsigned long long mig_stall_ticks;  // 100 MHz ticks without any progress of the frame after which a WAITING server gives up (sets mig[kMigStalled], leaves): the escape from a launch whose workgroups are not all resident; 0 = wait for ever
   unsigned mig_flags;           // bit 0: acquire (not relaxed) polling; bit 1: adaptive push threshold; bits 8-15: longest back-off of a waiting server in naps of ~3.4 us; bits 16-31: at most this many waiting servers (0 = no limit)
   int screen;                   // strict launches of brute-force layouts: 1 = conservative FMA screen in the object loop (kernel variant ARITH 2; same canvas), 0 = the reference's unfused discriminant for every object
   int n_boxes;                  // block boxes of a single-level culling layout (padded to kPad), the servers' first trip
@@ -113,6 +114,7 @@ enum : int {
   kMigItsTail = 72,
   kMigTCounterDry = 73,  // first wave that found the work counter dry
   kMigConverted = 74,  // dedicated server waves that turned into lane waves
+  kMigStalled = 95,    // a waiting server saw no progress of the frame for mig_stall_ticks and left holding a ticket: the canvas is INCOMPLETE (host: tor_api.cpp handoff_stalled)
   kMigPushNow = 80,    // line 5: the ADAPTIVE push threshold (lanes read it every bounce; idle servers lower it, pushers that meet a backlog raise it)
   kMigWords = 96
 };
@@ -149,6 +151,9 @@ hipError_t launch_encode_ipcm(const double* pixels, int nrows, int ncols, uint8_
 // increasing row order); frame = nrows x ncols x 3 float64 in image order (tor_shard_rows' mapping, inverted)
 hipError_t launch_gather_rows(const double* gathered, double* frame, int nrows, int ncols, int row_tile, int shard_count,
                               long long shard_stride, hipStream_t stream);
+// RCCL watchdog test (TOR_FAULT_INJECT=rccl_hang): a kernel that keeps `stream` busy until *flag != 0 (device-visible host
+// memory) or max_ticks of the 100 MHz clock have passed
+hipError_t launch_spin_until(volatile unsigned* flag, unsigned long long max_ticks, hipStream_t stream);
 hipError_t launch_selftest(int op, const double* x, const double* y, double* out0, double* out1, long long n,
                            hipStream_t stream);
 

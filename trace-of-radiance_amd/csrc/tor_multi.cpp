@@ -12,6 +12,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -35,6 +37,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -67,6 +71,8 @@ RcclApi* rccl() {
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+    api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
     api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
     api.Send = (decltype(api.Send))sym("ncclSend");
     api.Recv = (decltype(api.Recv))sym("ncclRecv");
@@ -185,13 +191,14 @@ thread_local std::string g_last_note;
 
 // TOR_FAULT_INJECT = comma list of rccl_init | rccl_xfer | peer: the named leg fails at that point (tests of the fallback
 // chain; on a 1-GPU box `rccl_init` also makes AUTO consider RCCL for a device list with repeated ordinals)
-struct FaultInjection { bool rccl_init = false, rccl_xfer = false, peer = false; };
+struct FaultInjection { bool rccl_init = false, rccl_xfer = false, peer = false, rccl_hang = false; };
 FaultInjection fault_injection() {
   FaultInjection f;
   if (const char* e = std::getenv("TOR_FAULT_INJECT")) {
     f.rccl_init = std::strstr(e, "rccl_init") != nullptr;
     f.rccl_xfer = std::strstr(e, "rccl_xfer") != nullptr;
     f.peer = std::strstr(e, "peer") != nullptr;
+    f.rccl_hang = std::strstr(e, "rccl_hang") != nullptr;
   }
   return f;
 }
@@ -295,37 +302,184 @@ int gather_host(const GatherJob& j) {
   return TOR_OK;
 }
 
+// ---- RCCL watchdog ----------------------------------------------------------------------------------------------
+// A collective that goes wrong on a fresh node usually does not FAIL, it HANGS: ncclCommInitAll never returns, or the
+// send/recv kernels spin for ever.  Neither gives AUTO's fallback chain anything to fall back from, so every wait of the
+// RCCL leg has a deadline:
+//   * device side: the streams are POLLED (hipStreamQuery) instead of synchronised; past the deadline the communicators
+//     are aborted (ncclCommAbort makes RCCL's kernels leave), the streams are drained and the leg fails with a reason;
+//   * host side: communicator creation + self-check run in a helper thread; if it does not come back in time it is
+//     abandoned (it owns everything it touches) and the device list is marked bad.
+// Deadlines: TOR_RCCL_TIMEOUT_MS for a transfer (default 10 s + 1 ms per MB), TOR_RCCL_INIT_TIMEOUT_MS for creation +
+// self-check (default 120 s).  TOR_FAULT_INJECT=rccl_hang replaces the transfer by a kernel that never ends on its own
+// (tests/test_gpu_round4.py).
+long env_ms(const char* name, long dflt) {
+  if (const char* e = std::getenv(name)) {
+    char* endp = nullptr;
+    const long v = std::strtol(e, &endp, 10);
+    if (endp != e && v > 0) return v;
+  }
+  return dflt;
+}
+
+// all streams idle -> hipSuccess; past the deadline -> hipErrorNotReady; a stream in error -> that error
+hipError_t wait_streams(const std::vector<TorContext*>& ctxs, long deadline_ms) {
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t0 = clk::now();
+  size_t k = 0;
+  unsigned spins = 0;
+  while (k < ctxs.size()) {
+    hipError_t e = hipSetDevice(ctxs[k]->device);
+    if (e == hipSuccess) e = hipStreamQuery(ctxs[k]->stream);
+    if (e == hipSuccess) { ++k; continue; }
+    if (e != hipErrorNotReady) return e;
+    (void)hipGetLastError();
+    if (std::chrono::duration<double, std::milli>(clk::now() - t0).count() > (double)deadline_ms) return hipErrorNotReady;
+    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (the first ~ms is polled hot: a 1080p gather takes 0.1 ms)
+  }
+  return hipSuccess;
+}
+
+// the injected hang: a kernel on the root's stream that leaves only when the host sets *flag (what ncclCommAbort does to
+// RCCL's kernels) -- or after 20 s on its own, so that a broken test cannot hold the GPU
+struct HangInjection {
+  volatile unsigned* flag = nullptr;
+  ~HangInjection() { if (flag) (void)hipHostFree((void*)flag); }
+  hipError_t start(hipStream_t stream) {
+    hipError_t e = hipHostMalloc((void**)&flag, 64, hipHostMallocDefault);
+    if (e != hipSuccess) { flag = nullptr; return e; }
+    *flag = 0u;
+    return launch_spin_until(flag, 2000000000ull, stream);
+  }
+  void release() { if (flag) *flag = 1u; }
+};
+
+constexpr int TOR_RCCL_TIMED_OUT = -1000;  // internal: rccl_group_gather's deadline expired (the caller aborts the communicators)
+
 // One grouped send/recv gather over the communicators of a single-process device list.  EVERY path out of here
-// closes the group and leaves all streams idle: an open group or a half-enqueued transfer would hang the next call.
+// closes the group; the streams are idle on TOR_OK and on every error except TOR_RCCL_TIMED_OUT.
 int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<TorContext*>& ctxs, const std::vector<const void*>& src,
-                      const std::vector<size_t>& bytes, char* dst_base, size_t dst_stride, bool inject_failure) {
+                      const std::vector<size_t>& bytes, char* dst_base, size_t dst_stride, bool inject_failure, HangInjection* hang) {
   const int N = (int)ctxs.size();
   TorContext* root = ctxs[0];
   ncclResult_t first = ncclSuccess;
   const char* where = "";
   auto note = [&](ncclResult_t r, const char* w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; where = w; } };
-  ncclResult_t r = api->GroupStart();
-  if (r != ncclSuccess) return fail_rccl(r, "ncclGroupStart");
-  for (int k = 1; k < N && first == ncclSuccess; ++k) {
-    if (bytes[(size_t)k] == 0) continue;
-    if (inject_failure && k == N - 1) { note(ncclInternalError, "TOR_FAULT_INJECT=rccl_xfer"); break; }
-    note(api->Send(src[(size_t)k], bytes[(size_t)k], ncclChar, 0, comms[(size_t)k], ctxs[(size_t)k]->stream), "ncclSend");
-    if (first != ncclSuccess) break;
-    note(api->Recv(dst_base + (size_t)k * dst_stride, bytes[(size_t)k], ncclChar, k, comms[0], root->stream), "ncclRecv");
+  size_t total = 0;
+  for (int k = 1; k < N; ++k) total += bytes[(size_t)k];
+  if (hang) {
+    HIP_TRY(hipSetDevice(root->device));
+    HIP_TRY(hang->start(root->stream));
+  } else {
+    ncclResult_t r = api->GroupStart();
+    if (r != ncclSuccess) return fail_rccl(r, "ncclGroupStart");
+    for (int k = 1; k < N && first == ncclSuccess; ++k) {
+      if (bytes[(size_t)k] == 0) continue;
+      if (inject_failure && k == N - 1) { note(ncclInternalError, "TOR_FAULT_INJECT=rccl_xfer"); break; }
+      note(api->Send(src[(size_t)k], bytes[(size_t)k], ncclChar, 0, comms[(size_t)k], ctxs[(size_t)k]->stream), "ncclSend");
+      if (first != ncclSuccess) break;
+      note(api->Recv(dst_base + (size_t)k * dst_stride, bytes[(size_t)k], ncclChar, k, comms[0], root->stream), "ncclRecv");
+    }
+    note(api->GroupEnd(), "ncclGroupEnd");
   }
-  note(api->GroupEnd(), "ncclGroupEnd");
-  // the sends are complete once the matching receives are; wait for all of it so that the streams are idle either way
-  hipError_t he = hipSuccess;
-  for (int k = 0; k < N; ++k) {
-    hipError_t e = hipSetDevice(ctxs[(size_t)k]->device);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctxs[(size_t)k]->stream);
-    if (e != hipSuccess && he == hipSuccess) he = e;
-  }
+  // the sends are complete once the matching receives are; wait for all of it -- with a deadline
+  const long deadline = env_ms("TOR_RCCL_TIMEOUT_MS", 10000 + (long)(total >> 20));
+  const hipError_t he = wait_streams(ctxs, deadline);
   (void)hipSetDevice(root->device);
+  if (he == hipErrorNotReady) {
+    fail(TOR_ERR_HIP, "RCCL gather: not complete after " + std::to_string(deadline) + " ms (TOR_RCCL_TIMEOUT_MS); communicators aborted");
+    return TOR_RCCL_TIMED_OUT;
+  }
   if (first != ncclSuccess) return fail_rccl(first, where);
-  if (he != hipSuccess) return fail_hip(he, "RCCL gather: stream synchronisation");
+  if (he != hipSuccess) return fail_hip(he, "RCCL gather: stream query");
   return TOR_OK;
 }
+
+// after a timed-out transfer: abort, then give the streams a moment to drain so that the next leg finds them idle
+void abort_comms(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<TorContext*>& ctxs, HangInjection* hang) {
+  if (hang) hang->release();
+  if (api && api->CommAbort)
+    for (ncclComm_t& c : comms)
+      if (c) { (void)api->CommAbort(c); c = nullptr; }
+  (void)wait_streams(ctxs, env_ms("TOR_RCCL_DRAIN_MS", 5000));
+  (void)hipSetDevice(ctxs[0]->device);
+}
+
+// ncclCommInitAll + self-check for one device list; runs in its own thread (see the watchdog comment).  Everything it
+// touches is owned by this object.
+struct CommSetup {
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;
+  int rc = TOR_OK;
+  std::string err;
+  std::vector<int> key;
+  std::vector<TorContext*> ctxs;   // default contexts: they live as long as the process
+  std::vector<ncclComm_t> comms;
+};
+
+void comm_setup_body(std::shared_ptr<CommSetup> st) {
+  RcclApi* api = rccl();
+  const int N = (int)st->key.size();
+  int check = TOR_OK;
+  std::vector<ncclComm_t> c((size_t)N, nullptr);
+  const ncclResult_t r = api->CommInitAll(c.data(), N, st->key.data());
+  if (r != ncclSuccess) check = fail_rccl(r, "ncclCommInitAll");
+  // self-check: device k sends kCheck bytes of value (k * 37 + i) & 0xff through the very same grouped send/recv code
+  constexpr size_t kCheck = 4096;
+  std::vector<DeviceBuffer> pat((size_t)N);
+  DeviceBuffer got;
+  std::vector<const void*> src((size_t)N, nullptr);
+  std::vector<size_t> bytes((size_t)N, kCheck);
+  std::vector<unsigned char> host(kCheck);
+  for (int k = 0; k < N && check == TOR_OK; ++k) {
+    for (size_t i = 0; i < kCheck; ++i) host[i] = (unsigned char)((k * 37 + (int)i) & 0xff);
+    hipError_t e = hipSetDevice(st->ctxs[(size_t)k]->device);
+    if (e == hipSuccess) e = pat[(size_t)k].ensure(kCheck);
+    if (e == hipSuccess) e = hipMemcpy(pat[(size_t)k].ptr, host.data(), kCheck, hipMemcpyHostToDevice);
+    if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: pattern upload");
+    src[(size_t)k] = pat[(size_t)k].ptr;
+  }
+  if (check == TOR_OK) {
+    hipError_t e = hipSetDevice(st->ctxs[0]->device);
+    if (e == hipSuccess) e = got.ensure(kCheck * (size_t)N);
+    if (e == hipSuccess) e = hipMemset(got.ptr, 0, kCheck * (size_t)N);
+    if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: receive buffer");
+  }
+  if (check == TOR_OK) {
+    check = rccl_group_gather(api, c, st->ctxs, src, bytes, (char*)got.ptr, kCheck, false, nullptr);
+    if (check == TOR_RCCL_TIMED_OUT) {
+      const std::string why = tor_last_error();
+      abort_comms(api, c, st->ctxs, nullptr);
+      check = fail(TOR_ERR_HIP, "RCCL self-check: " + why);
+    }
+  }
+  if (check == TOR_OK) {
+    std::vector<unsigned char> back(kCheck * (size_t)N);
+    hipError_t e = hipMemcpy(back.data(), got.ptr, back.size(), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: read back");
+    for (int k = 1; k < N && check == TOR_OK; ++k)
+      for (size_t i = 0; i < kCheck; ++i)
+        if (back[(size_t)k * kCheck + i] != (unsigned char)((k * 37 + (int)i) & 0xff)) {
+          check = fail(TOR_ERR_HIP, "RCCL self-check: rank " + std::to_string(k) + "'s pattern arrived corrupted");
+          break;
+        }
+  }
+  for (DeviceBuffer& b : pat) b.release();
+  got.release();
+  if (check != TOR_OK)
+    for (ncclComm_t& cc : c)
+      if (cc) { (void)api->CommDestroy(cc); cc = nullptr; }
+  std::lock_guard<std::mutex> lock(st->m);
+  st->rc = check;
+  if (check != TOR_OK) st->err = tor_last_error();
+  else st->comms = std::move(c);
+  st->done = true;
+  st->cv.notify_all();
+}
+
+thread_local int g_last_gather_leg = -1, g_last_rccl_ranks = 0, g_last_devices = 0, g_last_distinct = 0;
+thread_local std::vector<float> g_last_kernel_ms;
 
 // Single-process RCCL (ncclCommInitAll): every device sends its shard to devices[0] over its own xGMI link (7 links
 // in parallel, no ring).  A communicator is trusted only after a SELF-CHECK at creation: every device sends a 4 KB
@@ -333,60 +487,31 @@ int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::v
 int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
   if (fault.rccl_init) return fail(TOR_ERR_HIP, "TOR_FAULT_INJECT=rccl_init");
   RcclApi* api = rccl();
-  if (!api) return fail(TOR_ERR_HIP, "librccl.so.1 could not be loaded");
+  if (!api && !fault.rccl_hang) return fail(TOR_ERR_HIP, "librccl.so.1 could not be loaded");
   int rc = ensure_root_buffers(j);
   if (rc != TOR_OK) return rc;
   const int N = j.n();
   const std::vector<TorContext*>& ctxs = *j.ctxs;
   TorContext* root = ctxs[0];
   std::vector<ncclComm_t>* comms = nullptr;
-  {
+  std::vector<ncclComm_t> no_comms;  // (rccl_hang on a box without N distinct GPUs: no communicator, only the watchdog's path)
+  if (fault.rccl_hang) {
+    comms = &no_comms;
+  } else {
     std::lock_guard<std::mutex> lock(g_comm_mutex);
     auto it = g_single_process_comms.find(j.key);
     if (it == g_single_process_comms.end()) {
-      std::vector<ncclComm_t> c((size_t)N, nullptr);
-      RCCL_TRY(api->CommInitAll(c.data(), N, j.key.data()));
-      // self-check: device k sends kCheck bytes of value (k * 37 + i) & 0xff
-      constexpr size_t kCheck = 4096;
-      std::vector<DeviceBuffer> pat((size_t)N);
-      struct Free { std::vector<DeviceBuffer>& v; ~Free() { for (DeviceBuffer& b : v) b.release(); } } free_pat{pat};
-      std::vector<const void*> src((size_t)N, nullptr);
-      std::vector<size_t> bytes((size_t)N, kCheck);
-      std::vector<unsigned char> host(kCheck);
-      int check = TOR_OK;
-      for (int k = 0; k < N && check == TOR_OK; ++k) {
-        for (size_t i = 0; i < kCheck; ++i) host[i] = (unsigned char)((k * 37 + (int)i) & 0xff);
-        hipError_t e = hipSetDevice(ctxs[(size_t)k]->device);
-        if (e == hipSuccess) e = pat[(size_t)k].ensure(kCheck);
-        if (e == hipSuccess) e = hipMemcpy(pat[(size_t)k].ptr, host.data(), kCheck, hipMemcpyHostToDevice);
-        if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: pattern upload");
-        src[(size_t)k] = pat[(size_t)k].ptr;
-      }
-      DeviceBuffer got;
-      struct FreeOne { DeviceBuffer& b; ~FreeOne() { b.release(); } } free_got{got};
-      if (check == TOR_OK) {
-        hipError_t e = hipSetDevice(root->device);
-        if (e == hipSuccess) e = got.ensure(kCheck * (size_t)N);
-        if (e == hipSuccess) e = hipMemset(got.ptr, 0, kCheck * (size_t)N);
-        if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: receive buffer");
-      }
-      if (check == TOR_OK) check = rccl_group_gather(api, c, ctxs, src, bytes, (char*)got.ptr, kCheck, false);
-      if (check == TOR_OK) {
-        std::vector<unsigned char> back(kCheck * (size_t)N);
-        hipError_t e = hipMemcpy(back.data(), got.ptr, back.size(), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: read back");
-        for (int k = 1; k < N && check == TOR_OK; ++k)
-          for (size_t i = 0; i < kCheck; ++i)
-            if (back[(size_t)k * kCheck + i] != (unsigned char)((k * 37 + (int)i) & 0xff)) {
-              check = fail(TOR_ERR_HIP, "RCCL self-check: rank " + std::to_string(k) + "'s pattern arrived corrupted");
-              break;
-            }
-      }
-      if (check != TOR_OK) {
-        for (ncclComm_t cc : c) if (cc) (void)api->CommDestroy(cc);
-        return check;
-      }
-      it = g_single_process_comms.emplace(j.key, std::move(c)).first;
+      auto st = std::make_shared<CommSetup>();
+      st->key = j.key;
+      st->ctxs = ctxs;
+      std::thread(comm_setup_body, st).detach();
+      const long deadline = env_ms("TOR_RCCL_INIT_TIMEOUT_MS", 120000);
+      std::unique_lock<std::mutex> wait_lock(st->m);
+      if (!st->cv.wait_for(wait_lock, std::chrono::milliseconds(deadline), [&] { return st->done; }))
+        return fail(TOR_ERR_HIP, "RCCL: communicator creation + self-check did not return within " + std::to_string(deadline) +
+                                     " ms (TOR_RCCL_INIT_TIMEOUT_MS); abandoned");
+      if (st->rc != TOR_OK) return fail(st->rc, st->err);
+      it = g_single_process_comms.emplace(j.key, std::move(st->comms)).first;
     }
     comms = &it->second;
   }
@@ -397,8 +522,23 @@ int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
   std::vector<const void*> src((size_t)N, nullptr);
   std::vector<size_t> bytes((size_t)N, 0);
   for (int k = 0; k < N; ++k) { src[(size_t)k] = ctxs[(size_t)k]->scratch.ptr; bytes[(size_t)k] = j.shard_bytes(k); }
-  rc = rccl_group_gather(api, *comms, ctxs, src, bytes, gbase, j.slot_bytes(), fault.rccl_xfer);
+  HangInjection hang;
+  rc = rccl_group_gather(api, *comms, ctxs, src, bytes, gbase, j.slot_bytes(), fault.rccl_xfer, fault.rccl_hang ? &hang : nullptr);
+  if (rc == TOR_RCCL_TIMED_OUT) {
+    const std::string why = tor_last_error();
+    abort_comms(api, *comms, ctxs, fault.rccl_hang ? &hang : nullptr);
+    if (!fault.rccl_hang) {
+      std::lock_guard<std::mutex> lock(g_comm_mutex);
+      g_single_process_comms.erase(j.key);  // (aborted communicators are gone)
+    }
+    return fail(TOR_ERR_HIP, why);
+  }
   if (rc != TOR_OK) return rc;
+  g_last_rccl_ranks = 0;
+  if (api && api->CommCount && !comms->empty() && (*comms)[0]) {
+    int cnt = 0;
+    if (api->CommCount((*comms)[0], &cnt) == ncclSuccess) g_last_rccl_ranks = cnt;
+  }
   return assemble_and_download(j);
 }
 
@@ -435,7 +575,8 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
   std::vector<int> plan;
   if (o.gather == TOR_GATHER_AUTO) {
     const std::vector<int> key(o.devices, o.devices + N);
-    if ((distinct || fault.rccl_init) && (rccl() != nullptr || fault.rccl_init) && !rccl_known_bad(key)) plan.push_back(TOR_GATHER_RCCL);
+    const bool injected = fault.rccl_init || fault.rccl_hang;  // (a 1-GPU box walks the RCCL leg's failure paths this way)
+    if ((distinct || injected) && (rccl() != nullptr || injected) && !rccl_known_bad(key)) plan.push_back(TOR_GATHER_RCCL);
     plan.push_back(TOR_GATHER_PEER);
     plan.push_back(TOR_GATHER_HOST);
   } else {
@@ -484,6 +625,9 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
       rc = tor_render_device(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction, max_depth, &ok,
                              (double*)ctx->scratch.ptr, ctx->stream);
       if (rc != TOR_OK) return rc;
+      rc = rerender_if_stalled(ctx, cam, nrows, ncols, canvas->samples_per_pixel, canvas->gamma_correction, max_depth, &ok,
+                               (double*)ctx->scratch.ptr, ctx->stream);
+      if (rc != TOR_OK) return rc;
       if (mode == TOR_GATHER_HOST) {
         t_render[(size_t)k] = ms_since(t0);
         t0 = clk::now();
@@ -507,6 +651,12 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
   }
   for (int k = 0; k < N; ++k)
     if (rcs[(size_t)k] != TOR_OK) return fail(rcs[(size_t)k], "device " + std::to_string(o.devices[k]) + ": " + errs[(size_t)k]);
+  // the dominant kernel's duration on every device (HIP events around the launch, on the launch's stream): tor_last_device_kernel_ms
+  g_last_kernel_ms.assign((size_t)N, 0.f);
+  for (int k = 0; k < N; ++k) {
+    float ms = 0.f;
+    if (ctxs[(size_t)k]->timing_valid && tor_last_kernel_ms(ctxs[(size_t)k], &ms, nullptr) == TOR_OK) g_last_kernel_ms[(size_t)k] = ms;
+  }
   for (int k = 0; k < N; ++k) {
     if (t_upload[(size_t)k] > timing_ms[0]) timing_ms[0] = t_upload[(size_t)k];
     if (t_render[(size_t)k] > timing_ms[1]) timing_ms[1] = t_render[(size_t)k];
@@ -515,8 +665,12 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
   timing_ms[4] = 1.0;
   for (int k = 0; k < N; ++k)
     if (!hit[(size_t)k]) timing_ms[4] = 0.0;
+  g_last_devices = N;
+  g_last_distinct = distinct ? 1 : 0;
   if (mode == TOR_GATHER_HOST) {
     set_last_note("gather: host");
+    g_last_gather_leg = TOR_GATHER_HOST;
+    g_last_rccl_ranks = 0;
     return TOR_OK;
   }
 
@@ -539,11 +693,13 @@ int render_multi_device(TorCanvas* canvas, const TorCamera* cam, TorHittableList
     rc = m == TOR_GATHER_RCCL ? gather_rccl(job, fault) : (m == TOR_GATHER_PEER ? gather_peer(job, fault) : gather_host(job));
     if (rc == TOR_OK) {
       set_last_note(notes + "gather: " + gather_name(m));
+      g_last_gather_leg = m;
+      if (m != TOR_GATHER_RCCL) g_last_rccl_ranks = 0;
       break;
     }
     notes += std::string(gather_name(m)) + " failed (" + tor_last_error() + "); ";
     // AUTO never tries a communicator again that failed once (an injected failure says nothing about the communicator)
-    if (m == TOR_GATHER_RCCL && !fault.rccl_init && !fault.rccl_xfer) mark_rccl_bad(job.key);
+    if (m == TOR_GATHER_RCCL && !fault.rccl_init && !fault.rccl_xfer && !fault.rccl_hang) mark_rccl_bad(job.key);
   }
   if (rc != TOR_OK) return fail(rc, "tor_render: framebuffer gather: " + notes);
   timing_ms[2] = ms_since(t0);
@@ -562,6 +718,21 @@ using tor::fail_rccl;
 extern "C" {
 
 const char* tor_last_note(void) { return tor::last_note().c_str(); }
+
+int tor_last_gather_info(int32_t out[4]) {
+  if (!out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_gather_info: out is NULL");
+  out[0] = tor::g_last_gather_leg;
+  out[1] = tor::g_last_rccl_ranks;
+  out[2] = tor::g_last_devices;
+  out[3] = tor::g_last_distinct;
+  return TOR_OK;
+}
+
+int32_t tor_last_device_kernel_ms(float* out, int32_t cap) {
+  const int32_t n = (int32_t)tor::g_last_kernel_ms.size();
+  for (int32_t k = 0; out && k < n && k < cap; ++k) out[k] = tor::g_last_kernel_ms[(size_t)k];
+  return n;
+}
 
 int tor_comm_unique_id(uint8_t id_out[128]) {
   if (!id_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_comm_unique_id: NULL argument");
@@ -593,6 +764,27 @@ int tor_comm_destroy(TorContext* ctx) {
   if (api && ctx->comm->comm) (void)api->CommDestroy(ctx->comm->comm);
   delete ctx->comm;
   ctx->comm = nullptr;
+  return TOR_OK;
+}
+
+int tor_comm_abort(TorContext* ctx) {
+  if (!ctx || !ctx->comm) return TOR_OK;
+  tor::RcclApi* api = tor::rccl();
+  if (api && api->CommAbort && ctx->comm->comm) (void)api->CommAbort(ctx->comm->comm);
+  delete ctx->comm;
+  ctx->comm = nullptr;
+  return TOR_OK;
+}
+
+int tor_comm_count(TorContext* ctx, int32_t* ranks_out) {
+  if (!ctx || !ranks_out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_comm_count: NULL argument");
+  *ranks_out = 0;
+  if (!ctx->comm || !ctx->comm->comm) return TOR_OK;
+  tor::RcclApi* api = tor::rccl();
+  if (!api || !api->CommCount) return fail(TOR_ERR_HIP, "tor_comm_count: librccl.so.1 could not be loaded");
+  int n = 0;
+  RCCL_TRY(api->CommCount(ctx->comm->comm, &n));
+  *ranks_out = n;
   return TOR_OK;
 }
 
