@@ -456,6 +456,12 @@ TOR_API int tor_selftest_filter32_host(int64_t n, const double* o, const double*
 TOR_API int tor_selftest_screen_host(int64_t n, const double* o, const double* d, const double* c0,
                                      const double* dc, const int32_t* moving, const double* f, const double* r2,
                                      int32_t* keep, int32_t* need);
+/* The screen's SECOND form (expanded quadratic, direction normalised per ray: csrc/tor_screen.hpp).  variant 0: static
+ * spheres through the general record, movers along y through the common-height record, other movers through the first form
+ * (as the kernel routes them); variant 1: static spheres through the common-height record. */
+TOR_API int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const double* c0,
+                                      const double* dc, const int32_t* moving, const double* f, const double* r2,
+                                      int32_t variant, int32_t* keep, int32_t* need);
 
 /* Runs the kernel's own math on the DEVICE: op 0: sin,cos(a)  1: x^5  2: pow(x,y)
  * 3: sqrt(x)  4: x/y  5: uniform01 of seed(row=x,col=y) first n draws... see tests. */

@@ -489,7 +489,13 @@ def test_bench_multi_rank_path_on_one_gpu(tor):
     assert d["n_gpus"] == 2 and d["gathered_frame_identical_to_single_process"] is True
     # strong scaling is the default: the frame -- and its spp -- do not depend on N
     assert d["scaling"] == "strong" and "640x360, 4 spp" in d["config"]["workload"] and d["value"] > 0
-    assert d["cpu_baseline"]["value"] is None and "N = 1" in d["cpu_baseline"]["note"]
+    # round 4: the N > 1 line is self-contained -- CPU baseline (timed once the ranks are gone), kernel-level roofline
+    # (slowest rank's HIP-event kernel time, live PMC traffic of one shard's launch), the gather's rank count, the N = 1 value of the same run
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["c1"]["ppm_equals_reference_png"] is True
+    assert d["roofline"]["kernel_ms"] > 0 and len(d["roofline"]["kernel_ms_per_rank"]) == 2 and d["roofline"]["frac"] > 0
+    assert "traffic" in d["roofline"] and "traffic_scope" in d["roofline"]
+    assert d["rccl_ranks"] == 0 and d["gather"]["world"] == 2          # gloo on one GPU: no RCCL communicator in this run
+    assert d["single_gpu_same_run"]["value"] > 0 and d["single_gpu_same_run"]["frame_identical_to_gathered"] is True
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port + 1), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
                         "--warmup", "0", "--spp", "4", "--width", "640", "--height", "360", "--scaling", "weak", "--no-stats", "--no-pmc"],

@@ -27,6 +27,19 @@ def test_screen_never_drops_a_needed_object(tor, scale, r_lo, r_hi, origin):
     missed = np.flatnonzero((need != 0) & (keep == 0))
     assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
     assert np.count_nonzero(need) > n // 10
+    # the second form (expanded quadratic, normalised direction): general static records, common-height static records, and the
+    # movers cut down to motion along y (the only movers it takes)
+    for variant in (0, 1):
+        keep2, need2 = tor.selftest_screen2(o, d, c0, dc, moving, f, r2, variant)
+        missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
+        assert missed.size == 0, (variant, missed[:5], o[missed[:1]], d[missed[:1]], c0[missed[:1]])
+    dcy = dc.copy()
+    dcy[:, 0] = 0.0
+    dcy[:, 2] = 0.0
+    keep2, need2 = tor.selftest_screen2(o, d, c0, dcy, moving, f, r2, 0)
+    missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]], c0[missed[:1]], dcy[missed[:1]], f[missed[:1]])
+    assert np.count_nonzero(need2) > n // 10
 
 
 def test_screen_on_the_decision_boundary(tor):
@@ -60,6 +73,17 @@ def test_screen_on_the_decision_boundary(tor):
     missed = np.flatnonzero((need != 0) & (keep == 0))
     assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
     assert 0 < np.count_nonzero(need) < n            # both sides of the boundary are present
+    for variant in (0, 1):
+        keep2, need2 = tor.selftest_screen2(o, d, c0, np.zeros((n, 3)), moving, np.zeros(n), r * r, variant)
+        missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
+        assert missed.size == 0, (variant, missed[:5], o[missed[:1]], d[missed[:1]])
+    # the same pairs as movers along y caught at a time fraction f: centre = c0 - f dc + f dc
+    fm = rng.uniform(-0.5, 1.5, n)
+    dcm = np.column_stack([np.zeros(n), rng.uniform(-0.5, 0.5, n), np.zeros(n)])
+    keep2, need2 = tor.selftest_screen2(o, d, c0 - dcm * fm[:, None], dcm, np.ones(n, dtype=np.int32), fm, r * r, 0)
+    missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
+    assert 0 < np.count_nonzero(need2) < n
 
 
 def test_screen_drops_the_obvious(tor):
@@ -72,11 +96,17 @@ def test_screen_drops_the_obvious(tor):
     moving = np.ones(n, dtype=np.int32)
     o = np.column_stack([rng.uniform(-11, 11, n), rng.uniform(0.0, 2.0, n), rng.uniform(-11, 11, n)])
     d = _unit(rng, n)
-    keep, need = tor.selftest_screen(o, d, c0, dc, moving, rng.uniform(0, 1, n), np.full(n, 0.04))
+    fr = rng.uniform(0, 1, n)
+    keep, need = tor.selftest_screen(o, d, c0, dc, moving, fr, np.full(n, 0.04))
     assert np.count_nonzero((need != 0) & (keep == 0)) == 0
     extra = np.count_nonzero((keep != 0) & (need == 0))
     assert extra <= 4, extra        # only pairs within rounding distance of the boundary
     assert 50 < np.count_nonzero(keep) < 0.01 * n        # a ray meets few of the small spheres
+    keep2, need2 = tor.selftest_screen2(o, d, c0, dc, moving, fr, np.full(n, 0.04), 0)   # the second form is no blunter
+    assert np.array_equal(need2, need) and np.count_nonzero((need2 != 0) & (keep2 == 0)) == 0
+    assert np.count_nonzero((keep2 != 0) & (need2 == 0)) <= 4
+    keep3, need3 = tor.selftest_screen2(o, d, c0, dc * 0.0, moving * 0, fr, np.full(n, 0.04), 1)
+    assert np.count_nonzero((need3 != 0) & (keep3 == 0)) == 0 and np.count_nonzero((keep3 != 0) & (need3 == 0)) <= 4
 
 
 def test_screen_degenerate_rays(tor):
@@ -95,3 +125,7 @@ def test_screen_degenerate_rays(tor):
     keep, need = tor.selftest_screen(o, d, c0, dc, moving, f, r2)
     assert np.all((need == 0) | (keep != 0)), (keep, need)
     assert keep[1] and keep[2] and need[1] and need[2]
+    for variant in (0, 1):
+        keep2, need2 = tor.selftest_screen2(o, d, c0, dc, moving, f, r2, variant)
+        assert np.all((need2 == 0) | (keep2 != 0)), (variant, keep2, need2)
+        assert keep2[1] and keep2[2]

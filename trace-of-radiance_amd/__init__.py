@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
     "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
-    "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
+    "tor_selftest_screen2_host", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
 ]
 
 _lib = None
@@ -237,6 +237,8 @@ def lib():
         [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2
     L.tor_selftest_screen_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
         [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_int32)] * 2
+    L.tor_selftest_screen2_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)] + \
+        [C.POINTER(C.c_double)] * 2 + [C.c_int32] + [C.POINTER(C.c_int32)] * 2
     L.tor_selftest_slab32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int32)] * 2
     L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
@@ -708,6 +710,23 @@ def selftest_screen(o, d, c0, dc, moving, f, r2):
     _check(lib().tor_selftest_screen_host(n, o.ctypes.data_as(P), d.ctypes.data_as(P), c0.ctypes.data_as(P), dc.ctypes.data_as(P),
                                           moving.ctypes.data_as(I), f.ctypes.data_as(P), r2.ctypes.data_as(P), keep.ctypes.data_as(I),
                                           need.ctypes.data_as(I)))
+    return keep, need
+
+
+def selftest_screen2(o, d, c0, dc, moving, f, r2, variant=0):
+    """(keep, need): the screen's second form (expanded quadratic, normalised direction) on the host; variant 1 routes static
+    spheres through the common-height record."""
+    dp = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    o, d, c0, dc, f, r2 = dp(o), dp(d), dp(c0), dp(dc), dp(f), dp(r2)
+    moving = np.ascontiguousarray(moving, dtype=np.int32)
+    n = len(f)
+    keep = np.zeros(n, dtype=np.int32)
+    need = np.zeros(n, dtype=np.int32)
+    P = C.POINTER(C.c_double)
+    I = C.POINTER(C.c_int32)
+    _check(lib().tor_selftest_screen2_host(n, o.ctypes.data_as(P), d.ctypes.data_as(P), c0.ctypes.data_as(P), dc.ctypes.data_as(P),
+                                           moving.ctypes.data_as(I), f.ctypes.data_as(P), r2.ctypes.data_as(P), int(variant),
+                                           keep.ctypes.data_as(I), need.ctypes.data_as(I)))
     return keep, need
 
 

@@ -61,10 +61,11 @@ int fail_hip(hipError_t e, const char* what) {
 hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* cold_override) {
   const std::vector<double>& c = cold_override ? *cold_override : lay.cold;
   struct Part { const void* src; size_t bytes; size_t off; };
-  Part parts[7] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
+  Part parts[9] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
                    {lay.movy.data(), lay.movy.size() * 8, 0}, {lay.segs.data(), lay.segs.size() * 8, 0},
                    {c.data(), c.size() * 8, 0},               {lay.hot32.data(), lay.hot32.size() * 4, 0},
-                   {lay.coop_trips.data(), lay.coop_trips.size() * 8, 0}};
+                   {lay.coop_trips.data(), lay.coop_trips.size() * 8, 0},
+                   {lay.xsegs.data(), lay.xsegs.size() * 8, 0}, {lay.xrec.data(), lay.xrec.size() * 8, 0}};
   size_t total = 0;
   for (Part& p : parts) {
     p.off = total;
@@ -83,6 +84,8 @@ hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* c
   cold = (const double*)(b + parts[4].off);
   hot32 = (const float*)(b + parts[5].off);
   coop_trips = (const double*)(b + parts[6].off);
+  xsegs = (const double*)(b + parts[7].off);
+  xrec = (const double*)(b + parts[8].off);
   n_segs = lay.n_segs;
   n_sorted = (int)lay.n_sorted;
   has_f32 = false;
@@ -545,6 +548,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       q.segs = L.segs;
       q.cold = L.cold;
       q.hot32 = L.has_f32 ? L.hot32 : nullptr;
+      q.xsegs = L.xsegs;
+      q.xrec = L.xrec;
       q.n_segs = L.n_segs;
     };
     const bool blocks_avail = (accel & TOR_ACCEL_BLOCKS) && ctx->accel_built[v32] && ctx->accel[v32].available;
@@ -1365,6 +1370,40 @@ int tor_selftest_screen_host(int64_t n, const double* o, const double* d, const 
       if ((0.001 < s0 && s0 < INFINITY) || (0.001 < s1r && s1r < INFINITY)) nd |= 2;
     }
     need[i] = nd;
+  }
+  return TOR_OK;
+}
+
+// The SECOND form of the screen (tor_screen.hpp: expanded quadratic, normalised direction) on the host, same conventions as
+// tor_selftest_screen_host.  variant 0: a static sphere through the general record (kind 10), a mover along y through kind 12,
+// any other mover through the first form (as the kernel does); variant 1: static spheres through the common-height record (kind 11).
+int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const double* c0, const double* dc,
+                              const int32_t* moving, const double* f, const double* r2, int32_t variant, int32_t* keep, int32_t* need) {
+  if (n < 0 || !o || !d || !c0 || !dc || !moving || !f || !r2 || !keep || !need)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_selftest_screen2_host: bad argument");
+  int rc = tor_selftest_screen_host(n, o, d, c0, dc, moving, f, r2, keep, need);  // `need`, and `keep` of the pairs that stay on the first form
+  if (rc != TOR_OK) return rc;
+  auto up = [](double x) { return x * (1.0 + 0x1p-40); };
+  for (int64_t i = 0; i < n; ++i) {
+    const double* oo = o + 3 * i; const double* dd = d + 3 * i; const double* cc0 = c0 + 3 * i; const double* dcc = dc + 3 * i;
+    const bool mv = moving[i] != 0;
+    if (mv && !(dcc[0] == 0.0 && dcc[2] == 0.0)) continue;
+    const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];  // spheres.nim:30
+    const double reach = up(std::sqrt(cc0[0] * cc0[0] + cc0[1] * cc0[1] + cc0[2] * cc0[2]) + std::sqrt(std::fabs(r2[i])));
+    const double travel = mv ? up(std::sqrt(dcc[0] * dcc[0] + dcc[1] * dcc[1] + dcc[2] * dcc[2])) : 0.0;
+    const tor::ScreenRay ray = tor::screen2_ray(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a);
+    int word;
+    if (mv) {
+      const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, travel, cc0[1], f[i]);
+      word = tor::screen2_movy_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]), dcc[1], dcc[1] * dcc[1]);
+    } else if (variant == 1) {
+      const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, 0.0, cc0[1], 0.0);
+      word = tor::screen2_static_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]));
+    } else {
+      const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, 0.0, 0.0, 0.0);
+      word = tor::screen2_static(sg, cc0[0], cc0[1], cc0[2], tor::screen2_K(cc0[0], cc0[1], cc0[2], r2[i]));
+    }
+    keep[i] = word < 0 ? 1 : 0;
   }
   return TOR_OK;
 }

@@ -72,6 +72,7 @@ struct DeviceLayout {
   const double *stat = nullptr, *mov = nullptr, *movy = nullptr, *segs = nullptr, *cold = nullptr;
   const float* hot32 = nullptr;
   const double* coop_trips = nullptr;  // coop_pixel_kernel: 4 float64 per trip of 64 cold slots
+  const double *xsegs = nullptr, *xrec = nullptr;  // second form of the FMA screen (tor_scene.hpp)
   int n_segs = 0;
   int n_sorted = 0;  // cold slots (padded)
   bool has_f32 = false;

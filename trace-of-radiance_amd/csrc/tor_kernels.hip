@@ -560,9 +560,11 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       double best_f = 0.0;
       // ARITH 2 (conservative FMA screen, screen_filter above): the ray's share of the margins
       double scr_s1 = 0.0, scr_d1 = 0.0, scr_negmu = 0.0, scr_am = 0.0;
+      ScreenRay sray{};  // second form of the screen (tor_screen.hpp): the normalised direction, once per query
       if (kScreen) {
         scr_s1 = __builtin_fabs(ox) + __builtin_fabs(oy) + __builtin_fabs(oz);
         scr_d1 = __builtin_fabs(dx) + __builtin_fabs(dy) + __builtin_fabs(dz);
+        sray = screen2_ray(ox, oy, oz, dx, dy, dz, a_strict);
       }
 
       // TOR_ACCEL_F32: the ray in float32, relative to the scene origin (used by segment kinds 5-7 only)
@@ -608,7 +610,75 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           const int seg_count = seg_count_word & 0xffffff;   // padded to kBlock
           const int seg_real = seg_count - (seg_count_word >> 24);  // kinds 0-2: the objects that exist (the last block's tail is padding)
           const int seg_block0 = (int)segs[seg * 8 + 3];   // (first sorted index) / kBlock
-          if (seg_kind == 0) {
+          // ARITH 2: segments with second-form records (tor_screen.hpp: the quadratic expanded around the ray, direction
+          // normalised per ray -- 8 / 6 / 9 float64 instructions per object, all but one fused multiply-adds against scalar
+          // operands); the others keep the first form below
+          const int xkind = kScreen ? (int)as_const(p.xsegs)[seg * 8 + 0] : 0;
+          if (kScreen && xkind >= 10) {
+            const int x_first = (int)as_const(p.xsegs)[seg * 8 + 1];
+            double f = 0.0;
+            if (xkind == 12) f = (time - segs[seg * 8 + 4]) / segs[seg * 8 + 5];  // moving_spheres.nim:42
+            const ScreenSeg ss = screen2_seg(sray, segs[seg * 8 + 6], segs[seg * 8 + 7], as_const(p.xsegs)[seg * 8 + 2], f);
+            if (xkind == 12) {
+              cdptr rec = as_const(p.xrec) + ((long)x_first + 6 * (long)i);
+              double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+                const int n_live = seg_real - i;  // (wave-uniform)
+                if (n_live >= kBlock) {
+#pragma unroll
+                  for (int j = 0; j < kBlock; ++j) {
+                    const double c0 = n0, c1 = n1, c2 = n2, c3 = n3, c4 = n4;
+                    n0 = rec[6 * (j + 1) + 0]; n1 = rec[6 * (j + 1) + 1]; n2 = rec[6 * (j + 1) + 2];
+                    n3 = rec[6 * (j + 1) + 3]; n4 = rec[6 * (j + 1) + 4];
+                    m = push_bit(m, screen2_movy_y(ss, c0, c1, c2, c3, c4));
+                  }
+                } else {  // the last block: only its real objects
+#pragma unroll 1
+                  for (int j = 0; j < n_live; ++j) m = push_bit(m, screen2_movy_y(ss, rec[6 * j + 0], rec[6 * j + 1], rec[6 * j + 2], rec[6 * j + 3], rec[6 * j + 4]));
+                  m <<= (unsigned)(kBlock - n_live);
+                }
+                rec += 6 * kBlock;
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
+            } else {
+              cdptr rec = as_const(p.xrec) + ((long)x_first + 4 * (long)i);
+              double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+              for (; i < seg_count; i += kBlock) {
+                unsigned m = 0;
+                const int n_live = seg_real - i;  // (wave-uniform)
+                if (n_live >= kBlock) {
+                  if (xkind == 10) {
+#pragma unroll
+                    for (int j = 0; j < kBlock; ++j) {
+                      const double c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+                      n0 = rec[4 * (j + 1) + 0]; n1 = rec[4 * (j + 1) + 1]; n2 = rec[4 * (j + 1) + 2]; n3 = rec[4 * (j + 1) + 3];
+                      m = push_bit(m, screen2_static(ss, c0, c1, c2, c3));
+                    }
+                  } else {
+#pragma unroll
+                    for (int j = 0; j < kBlock; ++j) {
+                      const double c0 = n0, c1 = n1, c2 = n2;
+                      n0 = rec[4 * (j + 1) + 0]; n1 = rec[4 * (j + 1) + 1]; n2 = rec[4 * (j + 1) + 2];
+                      m = push_bit(m, screen2_static_y(ss, c0, c1, c2));
+                    }
+                  }
+                } else {  // the last block: only its real objects
+#pragma unroll 1
+                  for (int j = 0; j < n_live; ++j)
+                    m = push_bit(m, xkind == 10 ? screen2_static(ss, rec[4 * j + 0], rec[4 * j + 1], rec[4 * j + 2], rec[4 * j + 3])
+                                                : screen2_static_y(ss, rec[4 * j + 0], rec[4 * j + 1], rec[4 * j + 2]));
+                  m <<= (unsigned)(kBlock - n_live);
+                }
+                rec += 4 * kBlock;
+                q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
+                qn += (m != 0) ? 1u : 0u;
+                if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
+            }
+          } else if (seg_kind == 0) {
             // one base pointer per block, immediate offsets inside it, and the next record is
             // requested one object ahead of its use (s_load latency hides under ~17 VALU ops)
             cdptr rec = stat + 4 * (long)(seg_begin + i);

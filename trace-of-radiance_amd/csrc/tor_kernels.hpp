@@ -35,6 +35,8 @@ struct KParams {
   const double* movy;
   const double* segs;
   const double* cold;
+  const double* xsegs;  // per segment {xkind, first float64 of its records in xrec, common c0.y}: second form of the FMA screen (tor_screen.hpp, tor_scene.hpp)
+  const double* xrec;
   const float* hot32;  // TOR_ACCEL_F32 pair records, or null
   double org[3];       // origin of the float32 coordinates
   const double* bnd;   // TOR_ACCEL_BLOCKS: 8 float64 per block {lo xyz, hi xyz, 0, 0} (segment kind 3), else null

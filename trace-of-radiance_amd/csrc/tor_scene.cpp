@@ -9,6 +9,7 @@
 
 #include "tor_filter32.hpp"
 #include "tor_kernels.hpp"
+#include "tor_screen.hpp"
 
 namespace tor {
 
@@ -161,14 +162,61 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
       return false;
     }
   }
-  const size_t n_stat_p = padded(statics.size());
-  std::vector<char> yonly(groups.size(), 0), yonly32(groups32.size(), 0);
-  size_t n_mov_p = 0, n_movy_p = 0;
+  // ---- the float64 segments.  Statics and every (time0, time1) group of movers are cut once more by c0.y: members that share
+  // it bit for bit (spheres resting on a plane) form segments of their own when there are at least kPad of them -- the second
+  // form of the strict loop's FMA screen hoists their y terms out of the per-object work (tor_screen.hpp: kinds 11, 12).  The
+  // order of the objects is free (closest hit is order independent, ties go by the original index in the cold record).
+  struct Seg64 { int kind; std::vector<int64_t> ids; double t0, dt; int xkind; double y; };
+  std::vector<Seg64> segs64;
+  auto y_of = [&](int64_t i) { return objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.center.y : objs[i].u.moving_sphere.center0.y; };
+  auto cut_by_y = [&](const std::vector<int64_t>& members, int kind, double t0, double dt, int xkind_rest, int xkind_uniform) {
+    std::vector<std::pair<uint64_t, std::vector<int64_t>>> by_y;  // in order of first appearance
+    for (int64_t i : members) {
+      const double y = y_of(i);
+      uint64_t b;
+      std::memcpy(&b, &y, 8);
+      bool found = false;
+      for (auto& g : by_y)
+        if (g.first == b) { g.second.push_back(i); found = true; break; }
+      if (!found) by_y.push_back({b, {i}});
+      if (by_y.size() > 64) break;  // (a scene without common heights: do not search for them object by object)
+    }
+    std::vector<int64_t> rest;
+    std::vector<Seg64> uniform;
+    if (by_y.size() <= 64 && xkind_uniform != 0) {
+      for (auto& g : by_y)
+        if (g.second.size() >= (size_t)kPad && std::isfinite(y_of(g.second[0]))) uniform.push_back({kind, g.second, t0, dt, xkind_uniform, y_of(g.second[0])});
+      for (int64_t i : members) {
+        const double y = y_of(i);
+        bool in_uniform = false;
+        for (const Seg64& u : uniform) {
+          uint64_t a, b;
+          std::memcpy(&a, &y, 8); std::memcpy(&b, &u.y, 8);
+          if (a == b) { in_uniform = true; break; }
+        }
+        if (!in_uniform) rest.push_back(i);
+      }
+    } else {
+      rest = members;
+    }
+    if (!rest.empty()) segs64.push_back({kind, rest, t0, dt, xkind_rest, 0.0});
+    for (Seg64& u : uniform) segs64.push_back(std::move(u));
+  };
+  if (!statics.empty()) cut_by_y(statics, 0, 0.0, 1.0, 10, 11);
   for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const TorMovingSphere& first = objs[groups[gi].ids[0]].u.moving_sphere;
     const bool y = group_moves_along_y_only(objs, groups[gi]);
-    yonly[gi] = y ? 1 : 0;
-    (y ? n_movy_p : n_mov_p) += padded(groups[gi].ids.size());
+    const double t0 = first.time0, dt = first.time1 - first.time0;
+    // (kinds 1 / 2 without a second-form record keep the first form of the screen: xkind 0)
+    cut_by_y(groups[gi].ids, y ? 1 : 2, t0, dt, 0, (y && std::isfinite(t0) && std::isfinite(dt) && dt != 0.0) ? 12 : 0);
   }
+  size_t n_stat_p = 0, n_mov_p = 0, n_movy_p = 0, n_xrec = 0;
+  for (const Seg64& sg : segs64) {
+    const size_t cp = padded(sg.ids.size());
+    (sg.kind == 0 ? n_stat_p : (sg.kind == 1 ? n_movy_p : n_mov_p)) += cp;
+    n_xrec += cp * (sg.xkind == 12 ? 6 : (sg.xkind != 0 ? 4 : 0));
+  }
+  std::vector<char> yonly32(groups32.size(), 0);
   size_t n32_slots = padded(statics32.size()), n32_floats = padded(statics32.size()) / 2 * 10;
   for (size_t gi = 0; gi < groups32.size(); ++gi) {
     const bool y = group_moves_along_y_only(objs, groups32[gi]);
@@ -182,9 +230,11 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   out.stat.assign(4 * n_stat_p + 8, 0.0);
   out.mov.assign(8 * n_mov_p + 8, 0.0);
   out.movy.assign(6 * n_movy_p + 8, 0.0);
+  out.xrec.assign(n_xrec + 8, 0.0);
   out.hot32.assign(n32_floats + 32, 0.0f);
   out.cold.assign(16 * out.n_sorted + 16, 0.0);
   out.segs.clear();
+  out.xsegs.clear();
   // padding record: centre 0, radius^2 = -1  => discriminant <= -|d|^2 < 0, never a candidate
   for (size_t k = 0; k < n_stat_p; ++k) out.stat[4 * k + 3] = -1.0;
   for (size_t k = 0; k < n_mov_p; ++k) out.mov[8 * k + 3] = -1.0;
@@ -195,55 +245,65 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   // know about the segment's members (tor_kernels.hip: screen_filter) -- an upper bound of |c0| + |r| and of |c1 - c0|.  A
   // non-finite bound turns into infinite margins there: everything is kept and the exact test decides.
   auto up = [](double x) { return x * (1.0 + 0x1p-40); };
-  size_t sorted = 0;
-  if (!statics.empty()) {
-    double reach = 0.0;
-    for (size_t k = 0; k < statics.size(); ++k) {
-      const TorSphere& s = objs[statics[k]].u.sphere;
-      reach = std::fmax(reach, norm3(s.center.x, s.center.y, s.center.z) + std::fabs(s.radius));
-    }
-    // (segs[2] of kinds 0-2: padded count | padding records << 24 -- the kernel tests only the real objects of the last block)
-    out.segs.insert(out.segs.end(), {0.0, 0.0, (double)(n_stat_p | ((n_stat_p - statics.size()) << 24)), 0.0, 0.0, 0.0, up(reach), 0.0});
-    for (size_t k = 0; k < statics.size(); ++k) {
-      const TorSphere& s = objs[statics[k]].u.sphere;
-      out.stat[4 * k + 0] = s.center.x; out.stat[4 * k + 1] = s.center.y; out.stat[4 * k + 2] = s.center.z;
-      out.stat[4 * k + 3] = s.radius * s.radius;
-      if (!fill_cold(&out.cold[16 * (sorted + k)], objs[statics[k]], statics[k])) { err = "unknown Material kind"; return false; }
-    }
-    sorted += n_stat_p;
-  }
-  size_t mov_rec = 0, movy_rec = 0;
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    auto& g = groups[gi];
-    const size_t cnt_p = padded(g.ids.size());
-    const TorMovingSphere& first = objs[g.ids[0]].u.moving_sphere;
-    const double t0 = first.time0, dt = first.time1 - first.time0;
-    const bool y = yonly[gi] != 0;
+  size_t sorted = 0, stat_rec = 0, mov_rec = 0, movy_rec = 0, x_off = 0;
+  for (const Seg64& sg : segs64) {
+    const size_t cnt_p = padded(sg.ids.size());
     double reach = 0.0, travel = 0.0;
-    for (int64_t idx : g.ids) {
-      const TorMovingSphere& s = objs[idx].u.moving_sphere;
-      reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
-      travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
-    }
-    out.segs.insert(out.segs.end(), {y ? 1.0 : 2.0, (double)(y ? movy_rec : mov_rec), (double)(cnt_p | ((cnt_p - g.ids.size()) << 24)),
-                                     (double)(sorted / kPad), t0, dt, up(reach), up(travel)});
-    for (size_t k = 0; k < g.ids.size(); ++k) {
-      const TorMovingSphere& s = objs[g.ids[k]].u.moving_sphere;
-      const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
-      if (y) {
-        double* m = &out.movy[6 * (movy_rec + k)];
-        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
-        m[3] = s.radius * s.radius;
-        m[4] = dcy;
+    for (int64_t idx : sg.ids) {
+      if (sg.kind == 0) {
+        const TorSphere& s = objs[idx].u.sphere;
+        reach = std::fmax(reach, norm3(s.center.x, s.center.y, s.center.z) + std::fabs(s.radius));
       } else {
-        double* m = &out.mov[8 * (mov_rec + k)];
-        m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
-        m[3] = s.radius * s.radius;
-        m[4] = dcx; m[5] = dcy; m[6] = dcz;
+        const TorMovingSphere& s = objs[idx].u.moving_sphere;
+        reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
+        travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
       }
-      if (!fill_cold(&out.cold[16 * (sorted + k)], objs[g.ids[k]], g.ids[k])) { err = "unknown Material kind"; return false; }
     }
-    (y ? movy_rec : mov_rec) += cnt_p;
+    const size_t first_rec = sg.kind == 0 ? stat_rec : (sg.kind == 1 ? movy_rec : mov_rec);
+    // (segs[2] of kinds 0-2: padded count | padding records << 24 -- the kernel tests only the real objects of the last block)
+    out.segs.insert(out.segs.end(), {(double)sg.kind, (double)first_rec, (double)(cnt_p | ((cnt_p - sg.ids.size()) << 24)), (double)(sorted / kPad),
+                                     sg.kind == 0 ? 0.0 : sg.t0, sg.kind == 0 ? 0.0 : sg.dt, up(reach), up(travel)});
+    // second-form records of the screen (tor_screen.hpp): {xkind, first float64 of the records, common c0.y}
+    out.xsegs.insert(out.xsegs.end(), {(double)sg.xkind, (double)x_off, sg.y, 0.0, 0.0, 0.0, 0.0, 0.0});
+    const size_t xs = sg.xkind == 12 ? 6 : (sg.xkind != 0 ? 4 : 0);
+    for (size_t k = 0; k < cnt_p && xs != 0; ++k) {  // padding: never a candidate (t'' = T - 1e300 < 0, disc'' < 0), except for a wild ray, which the exact test rejects
+      double* x = &out.xrec[x_off + xs * k];
+      x[sg.xkind == 10 ? 3 : 2] = 1e300;
+    }
+    for (size_t k = 0; k < sg.ids.size(); ++k) {
+      const TorHittableVariant& hv = objs[sg.ids[k]];
+      if (sg.kind == 0) {
+        const TorSphere& s = hv.u.sphere;
+        double* m = &out.stat[4 * (stat_rec + k)];
+        m[0] = s.center.x; m[1] = s.center.y; m[2] = s.center.z;
+        m[3] = s.radius * s.radius;
+        double* x = &out.xrec[x_off + 4 * k];
+        if (sg.xkind == 10) { x[0] = s.center.x; x[1] = s.center.y; x[2] = s.center.z; x[3] = screen2_K(s.center.x, s.center.y, s.center.z, s.radius * s.radius); }
+        else { x[0] = s.center.x; x[1] = s.center.z; x[2] = screen2_Ky(s.center.x, s.center.z, s.radius * s.radius); x[3] = 0.0; }
+      } else {
+        const TorMovingSphere& s = hv.u.moving_sphere;
+        const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
+        if (sg.kind == 1) {
+          double* m = &out.movy[6 * (movy_rec + k)];
+          m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+          m[3] = s.radius * s.radius;
+          m[4] = dcy;
+          if (sg.xkind == 12) {
+            double* x = &out.xrec[x_off + 6 * k];
+            x[0] = s.center0.x; x[1] = s.center0.z; x[2] = screen2_Ky(s.center0.x, s.center0.z, s.radius * s.radius);
+            x[3] = dcy; x[4] = dcy * dcy; x[5] = 0.0;
+          }
+        } else {
+          double* m = &out.mov[8 * (mov_rec + k)];
+          m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
+          m[3] = s.radius * s.radius;
+          m[4] = dcx; m[5] = dcy; m[6] = dcz;
+        }
+      }
+      if (!fill_cold(&out.cold[16 * (sorted + k)], hv, sg.ids[k])) { err = "unknown Material kind"; return false; }
+    }
+    (sg.kind == 0 ? stat_rec : (sg.kind == 1 ? movy_rec : mov_rec)) += cnt_p;
+    x_off += cnt_p * xs;
     sorted += cnt_p;
   }
 
@@ -284,6 +344,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     }
     out.segs.insert(out.segs.end(), {(double)kind, (double)f_off, (double)cnt_p, (double)(sorted / kPad), t0, dt,
                                      (double)f32_round_up(mc0max * 1.000001), (double)f32_round_up(dcmax * 1.000001)});
+    out.xsegs.insert(out.xsegs.end(), 8, 0.0);  // (the two tables stay parallel)
     f_off += cnt_p / 2 * (size_t)stride;
     sorted += cnt_p;
     return true;
@@ -295,6 +356,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   }
   out.n_segs = (int)(out.segs.size() / 8);
   if (out.segs.empty()) out.segs.assign(8, 0.0);
+  if (out.xsegs.empty()) out.xsegs.assign(8, 0.0);
   // trip table of the one-wave-per-pixel kernel
   const size_t n_trips = (out.n_sorted + 63) / 64;
   out.coop_trips.assign(4 * n_trips + 4, 0.0);

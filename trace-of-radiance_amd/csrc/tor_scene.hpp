@@ -14,6 +14,10 @@ namespace tor {
 // Brute-force layout of a subset of the objects (tor_kernels.hpp: stat / movy / mov / segs / cold).
 struct HostLayout {
   std::vector<double> stat, mov, movy, segs, cold;
+  // second form of the strict loop's FMA screen (tor_screen.hpp): per segment {xkind (0: none, 10 static, 11 static with a
+  // common c0.y, 12 mover along y with a common c0.y), first float64 of its records in xrec, the common c0.y, 0...}; records
+  // {cx, cy, cz, K} | {cx, cz, K', 0} | {cx, cz, K', dcy, dcy^2, 0}, padded like the first form's
+  std::vector<double> xsegs, xrec;
   std::vector<float> hot32;  // TOR_ACCEL_F32 segments (kinds 5/6/7): packed pair records, see tor_kernels.hpp
   int n_segs = 0;
   size_t n_sorted = 0;  // cold slots (padded)
