@@ -593,9 +593,25 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       unsigned box_group0 = 0;  // index of the first group of 8 boxes (first box / 8)
       int seg = 0;
       int i = 0;
+      // kWords (the ARITH 2 variants: strict brute force behind the FMA screen): the candidate bits of 32 consecutive slots
+      // travel in ONE word per lane -- the v_alignbit of every test shifts the running mask, nothing else happens per block of 8 --
+      // and word k of a pass over the objects goes to LDS slot k unconditionally: no queue counter, no compaction, no overflow
+      // test per block (6 VALU instructions and a ballot per 8 objects before; 3 per 32 now).  A 16-bit summary (one bit per
+      // word, set when the word is not empty) lets the resolve pass skip the empty ones.  Scenes of more than 16 words (512
+      // slots) take several passes: the `full` mechanism of the queue, wave-uniform here.
+      constexpr bool kWords = kScreen;
+      // the time fraction of the last moving segment this query walked, for the resolve pass: a candidate of the same
+      // (time0, time1 - time0) -- bit patterns -- takes it instead of dividing again (moving_spheres.nim:42: same operands, same quotient)
+      double fc_f = 0.0;
+      unsigned long long fc_t0 = 0x7ff8dead00000001ull, fc_dt = 0x7ff8dead00000002ull;  // (NaN patterns no object carries)
+      unsigned mw = 0;      // the running mask
+      int w_base = 0;       // first word of the current pass (words = slots / 32 over the whole sorted list)
       for (;;) {
         unsigned qn = 0;
         bool full = false;
+        unsigned nz = 0;    // kWords: bit (w_count - 1 - k) <-> word k of this pass is not empty
+        int w_count = 0;    // kWords: words stored in this pass (wave-uniform)
+        int gb_next = 0;    // kWords: the block index behind the last block tested (wave-uniform)
         // (seg, i) are the same in every lane that has a live path, but they are updated under `if (active)` inside
         // this loop, which makes them divergent in the compiler's eyes -- and the object records would then come
         // through vector loads instead of the scalar data path (measured: half the speed).  readfirstlane inside
@@ -603,6 +619,20 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         if (active) {
         seg = __builtin_amdgcn_readfirstlane(seg);
         i = __builtin_amdgcn_readfirstlane(i);
+        if (kWords) w_base = __builtin_amdgcn_readfirstlane(w_base);
+        // end of a block of 8 in the kWords variants: the mask lives on in mw; behind every 4th block of the sorted list the word is stored
+#define TOR_WORDS_END_BLOCK()                                                  \
+        {                                                                      \
+          mw = m;                                                              \
+          const int gb_ = seg_block0 + i / kBlock;                             \
+          gb_next = gb_ + 1;                                                   \
+          if ((gb_ & 3) == 3) {                                                \
+            q[(unsigned)w_count * 64] = m;                                     \
+            nz = push_cond(nz, m != 0u);                                       \
+            w_count += 1;                                                      \
+            if (w_count == kQCap) { full = true; i += kBlock; break; }         \
+          }                                                                    \
+        }
         while (seg < p.n_segs) {
           const int seg_kind = (int)segs[seg * 8 + 0];
           const int seg_begin = (int)segs[seg * 8 + 1];    // first hot record of the segment
@@ -617,13 +647,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           if (kScreen && xkind >= 10) {
             const int x_first = (int)as_const(p.xsegs)[seg * 8 + 1];
             double f = 0.0;
-            if (xkind == 12) f = (time - segs[seg * 8 + 4]) / segs[seg * 8 + 5];  // moving_spheres.nim:42
+            if (xkind == 12) {
+              f = (time - segs[seg * 8 + 4]) / segs[seg * 8 + 5];  // moving_spheres.nim:42
+              fc_f = f; fc_t0 = double_to_bits(segs[seg * 8 + 4]); fc_dt = double_to_bits(segs[seg * 8 + 5]);
+            }
             const ScreenSeg ss = screen2_seg(sray, segs[seg * 8 + 6], segs[seg * 8 + 7], as_const(p.xsegs)[seg * 8 + 2], f);
             if (xkind == 12) {
               cdptr rec = as_const(p.xrec) + ((long)x_first + 6 * (long)i);
               double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
                 const int n_live = seg_real - i;  // (wave-uniform)
                 if (n_live >= kBlock) {
 #pragma unroll
@@ -639,15 +672,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   m <<= (unsigned)(kBlock - n_live);
                 }
                 rec += 6 * kBlock;
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             } else {
               cdptr rec = as_const(p.xrec) + ((long)x_first + 4 * (long)i);
               double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
                 const int n_live = seg_real - i;  // (wave-uniform)
                 if (n_live >= kBlock) {
                   if (xkind == 10) {
@@ -673,9 +709,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   m <<= (unsigned)(kBlock - n_live);
                 }
                 rec += 4 * kBlock;
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             }
           } else if (seg_kind == 0) {
@@ -685,7 +724,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
             if (kScreen) screen_margins(scr_s1 + segs[seg * 8 + 6], scr_d1, a, scr_negmu, scr_am);
             for (; i < seg_count; i += kBlock) {
-              unsigned m = 0;
+              unsigned m = kWords ? mw : 0u;
               const int n_live = seg_real - i;  // (wave-uniform)
               if (n_live >= kBlock) {
 #pragma unroll
@@ -708,9 +747,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 m <<= (unsigned)(kBlock - n_live);
               }
               rec += 4 * kBlock;
+              if constexpr (kWords) TOR_WORDS_END_BLOCK()
+              else {
               q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
               qn += (m != 0) ? 1u : 0u;
               if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+              }
             }
           } else if (F32 && seg_kind >= 5) {
             // TOR_ACCEL_F32 (tor_filter32.hpp): conservative packed-float32 discriminant, two objects per
@@ -723,7 +765,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             cfptr rec = (cfptr)(uintptr_t)p.hot32 + ((long)seg_begin + (long)(i / 2) * stride);
             if (seg_kind == 5) {
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
 #pragma unroll
                 for (int j = 0; j < kBlock / 2; ++j) {
                   cfptr r = rec + 10 * j;
@@ -732,13 +774,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 }
                 rec += 10 * (kBlock / 2);
                 m |= s32.wild;
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             } else if (seg_kind == 6) {
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
 #pragma unroll
                 for (int j = 0; j < kBlock / 2; ++j) {
                   cfptr r = rec + 12 * j;
@@ -748,13 +793,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 }
                 rec += 12 * (kBlock / 2);
                 m |= s32.wild;
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             } else {
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
 #pragma unroll
                 for (int j = 0; j < kBlock / 2; ++j) {
                   cfptr r = rec + 16 * j;
@@ -765,9 +813,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                 }
                 rec += 16 * (kBlock / 2);
                 m |= s32.wild;
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             }
           } else if (F32 && BLOCKS && (seg_kind == 3 || seg_kind == 4)) {
@@ -777,7 +828,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               box_kind = seg_kind;
               box_group0 = (unsigned)seg_block0;
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j)
                   m = push_cond(m, slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
@@ -793,7 +844,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               }
             } else
             for (; i < seg_count; i += kBlock) {
-              unsigned m = 0;
+              unsigned m = kWords ? mw : 0u;
 #pragma unroll
               for (int j = 0; j < kBlock; ++j)
                 m = push_cond(m, slab_bit32(b32, (f2v){rec[8 * j + 0], rec[8 * j + 1]}, (f2v){rec[8 * j + 2], rec[8 * j + 3]},
@@ -820,7 +871,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
             cdptr rec = as_const(p.bnd) + 8 * (long)(seg_begin + i);
             for (; i < seg_count; i += kBlock) {
-              unsigned m = 0;
+              unsigned m = kWords ? mw : 0u;
 #pragma unroll
               for (int j = 0; j < kBlock; ++j) {
                 const double tx0 = (rec[8 * j + 0] - ox) * ix, tx1 = (rec[8 * j + 3] - ox) * ix;
@@ -841,6 +892,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             // moving_spheres.nim:39-44: f = (time - time0) / (time1 - time0)
             const double t0 = segs[seg * 8 + 4], dt = segs[seg * 8 + 5];
             const double f = (time - t0) / dt;
+            fc_f = f; fc_t0 = double_to_bits(t0); fc_dt = double_to_bits(dt);
             if (kScreen) screen_margins(scr_s1 + segs[seg * 8 + 6] + segs[seg * 8 + 7] * __builtin_fabs(f), scr_d1, a, scr_negmu, scr_am);
             const double neg_f = -f;
             if (seg_kind == 1) {
@@ -849,7 +901,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
               cdptr rec = movy + 6 * (long)(seg_begin + i);
               double n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
                 const int n_live = seg_real - i;  // (wave-uniform)
                 auto test_y = [&](double c0x, double c0y, double c0z, double r2, double dcy) {
                   if (kScreen) {
@@ -874,13 +926,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                   m <<= (unsigned)(kBlock - n_live);
                 }
                 rec += 6 * kBlock;
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             } else {
               for (; i < seg_count; i += kBlock) {
-                unsigned m = 0;
+                unsigned m = kWords ? mw : 0u;
                 const int n_live = seg_real - i;  // (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < kBlock; ++j) {
@@ -901,15 +956,27 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
                     m = push_bit(m, disc_filter<ARITH>(ox, oy, oz, dx, dy, dz, a, cx, cy, cz, mov[8 * k + 3]));
                   }
                 }
+                if constexpr (kWords) TOR_WORDS_END_BLOCK()
+                else {
                 q[qn * 64] = ((unsigned)(seg_block0 + i / kBlock) << 8) | m;
                 qn += (m != 0) ? 1u : 0u;
                 if (ballot64(qn >= (unsigned)kQCap) != 0) { full = true; i += kBlock; break; }
+                }
               }
             }
           }
           if (full) break;
           seg += 1;
           i = 0;
+        }
+#undef TOR_WORDS_END_BLOCK
+        if (kWords) {
+          if (!full && (gb_next & 3) != 0) {  // the list ended inside a word: its bits move up into place
+            mw <<= (unsigned)(8 * (4 - (gb_next & 3)));
+            q[(unsigned)w_count * 64] = mw;
+            nz = push_cond(nz, mw != 0u);
+            w_count += 1;
+          }
         }
         }  // if (active)
 
@@ -1309,7 +1376,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           double cx = c[0], cy = c[1], cz = c[2], f = 0.0;
           const int flags = (int)__double_as_longlong(c[13]);
           if (flags & 1) {
-            f = (time - c[7]) / c[8];
+            const double ct0 = c[7], cdt = c[8];
+            if (double_to_bits(ct0) == fc_t0 && double_to_bits(cdt) == fc_dt) f = fc_f;
+            else f = (time - ct0) / cdt;
             if (ARITH != 1) {
               cx = cx + c[3] * f; cy = cy + c[4] * f; cz = cz + c[5] * f;
             } else {
@@ -1318,6 +1387,29 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }
           exact_hit(cx, cy, cz, c[15], slot, f);
         };
+        if constexpr (kWords) {
+          // words: bit (31 - j) of word k <-> cold slot (w_base + k) * 32 + j
+          unsigned cur_mask = 0, cur_base = 0, nzr = nz;
+          const int n_words = __builtin_amdgcn_readfirstlane(w_count), word0 = __builtin_amdgcn_readfirstlane(w_base);
+          for (;;) {
+            if (cur_mask == 0 && nzr != 0) {
+              const int b = 31 - __builtin_clz(nzr);
+              nzr &= ~(1u << b);
+              const unsigned k = (unsigned)(n_words - 1 - b);
+              cur_mask = q[k * 64];
+              cur_base = ((unsigned)word0 + k) * 32u;
+            }
+            const bool has = cur_mask != 0;
+            if (ballot64(has) == 0) break;
+            if (prof && lane == 0) prof_lds[kSecTrips] += 1;
+            if (has) {
+              const int b = 31 - __builtin_clz(cur_mask);
+              cur_mask &= ~(1u << b);
+              if (stats_on) atomicAdd(&prof_lds[kStCand], 1ull);
+              exact_cold(cur_base + (unsigned)(31 - b));
+            }
+          }
+        } else {
         unsigned kq = 0, cur_mask = 0, cur_block = 0, cur_is_bound = 0;
         for (;;) {
           if (cur_mask == 0 && kq < qn) {
@@ -1405,9 +1497,11 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             }
           }
         }
+        }  // (queue entries)
         }  // per-lane resolve
         TOR_SEC(kSecResolve)
         if (ballot64(active && full) == 0) break;
+        if (kWords) w_base += kQCap;
       }
       if (kCoop) {  // the closest hit the wave found for this lane's ray
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
