@@ -228,6 +228,11 @@ TOR_API int tor_render_opt(TorCanvas* canvas, const TorCamera* cam, TorHittableL
  * D2H / gather into canvas->pixels, out[3] whole call.  out[4] = 1 when the scene came from the cache. */
 TOR_API int tor_last_render_timing(double out[5]);
 
+/* The library's environment knobs -- ONE table (csrc/tor_knobs.hpp; KNOBS.md is generated from it): name, default, accepted
+ * values, when it is read ("call" | "context" | "upload") and what it does.  Strings are static. */
+TOR_API int32_t tor_knob_count(void);
+TOR_API int tor_knob_info(int32_t i, const char** name, const char** dflt, const char** range, const char** when, const char** what);
+
 /* Thread-local description of the last failure (never NULL). */
 TOR_API const char* tor_last_error(void);
 

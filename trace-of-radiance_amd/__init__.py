@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
     "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
-    "tor_selftest_screen2_host", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
+    "tor_selftest_screen2_host", "tor_knob_count", "tor_knob_info", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
 ]
 
 _lib = None
@@ -252,6 +252,8 @@ def lib():
     L.tor_render_gather_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int64,
                                            C.POINTER(Options), C.c_int32, C.c_void_p, C.c_void_p]
     L.tor_context_scene_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.tor_knob_count.restype = C.c_int32
+    L.tor_knob_info.argtypes = [C.c_int32] + [C.POINTER(C.c_char_p)] * 5
     L.tor_last_gather_info.argtypes = [C.POINTER(C.c_int32)]
     L.tor_last_device_kernel_ms.argtypes = [C.POINTER(C.c_float), C.c_int32]
     L.tor_last_device_kernel_ms.restype = C.c_int32
@@ -455,6 +457,16 @@ def last_render_timing() -> dict:
 def last_note() -> str:
     """What the last multi-device render() on this thread chose / fell back to (tor_last_note)."""
     return lib().tor_last_note().decode("utf-8", "replace")
+
+
+def knobs() -> list:
+    """The library's environment knobs (csrc/tor_knobs.hpp): dicts {name, default, range, when, what}."""
+    out = []
+    for i in range(int(lib().tor_knob_count())):
+        f = [C.c_char_p() for _ in range(5)]
+        _check(lib().tor_knob_info(i, *[C.byref(x) for x in f]))
+        out.append(dict(zip(("name", "default", "range", "when", "what"), (x.value.decode() for x in f))))
+    return out
 
 
 def last_gather_info() -> dict:

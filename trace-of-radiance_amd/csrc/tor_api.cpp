@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "tor_context.hpp"
+#include "tor_knobs.hpp"
 #include "tor_screen.hpp"
 
 // ---- layout guards: the structs must match what Nim's C backend emits --------
@@ -141,7 +142,7 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
     // shim of INTEGRATION.md) steers the library through the environment.  None of these changes a pixel.
     o.accel = TOR_ACCEL_BLOCKS | TOR_ACCEL_F32;  // exact accelerations on by default for the drop-in
     // (a malformed value is an error, not a silent fall-back to one GPU / the default: ADVICE r2)
-    if (const char* e = std::getenv("TOR_DEFAULT_ACCEL")) {
+    if (const char* e = tor::knob("TOR_DEFAULT_ACCEL")) {
       char* endp = nullptr;
       const long v = std::strtol(e, &endp, 10);
       if (endp != e && *endp == 0 && v >= 0 && v <= (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) o.accel = (int32_t)v;
@@ -152,17 +153,17 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
     // BASELINE.json's north_star, seed(row, col, sample): render.nim:59-60 re-seeds per pixel "to be able to parallelize the
     // outer loops"; this is the same idea one level down, and it is what lets 8 GPUs share a 1080p frame.  It is
     // the one knob of this list that changes pixels (a different, equally valid sample set; oracle mode SAMPLE / QUANTIZED).
-    if (const char* e = std::getenv("TOR_DEFAULT_SEEDING")) {
+    if (const char* e = tor::knob("TOR_DEFAULT_SEEDING")) {
       if (!std::strcmp(e, "sample")) o.seeding = TOR_SEED_SAMPLE;
       else if (!std::strcmp(e, "pixel")) o.seeding = TOR_SEED_PIXEL;
       else return no("TOR_DEFAULT_SEEDING must be pixel or sample");
     }
-    if (const char* e = std::getenv("TOR_DEVICES")) {
+    if (const char* e = tor::knob("TOR_DEVICES")) {
       TorOptions t = o;
       if (parse_device_list(e, t)) o = t;
       else return no("TOR_DEVICES must be \"all\" or a comma list of HIP device ordinals that exist (at most TOR_MAX_DEVICES)");
     }
-    if (const char* e = std::getenv("TOR_GATHER")) {
+    if (const char* e = tor::knob("TOR_GATHER")) {
       if (!std::strcmp(e, "rccl")) o.gather = TOR_GATHER_RCCL;
       else if (!std::strcmp(e, "peer")) o.gather = TOR_GATHER_PEER;
       else if (!std::strcmp(e, "host")) o.gather = TOR_GATHER_HOST;
@@ -286,7 +287,20 @@ extern "C" {
 
 const char* tor_last_error(void) { return g_last_error.c_str(); }
 
-const char* tor_version(void) { return "tor_mi355x 0.2 (gfx950)"; }
+const char* tor_version(void) { return "tor_mi355x 0.4 (gfx950)"; }
+
+int32_t tor_knob_count(void) { return tor::kKnobCount; }
+
+int tor_knob_info(int32_t i, const char** name, const char** dflt, const char** range, const char** when, const char** what) {
+  if (i < 0 || i >= tor::kKnobCount) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_knob_info: index out of range");
+  const tor::Knob& k = tor::kKnobs[i];
+  if (name) *name = k.name;
+  if (dflt) *dflt = k.dflt;
+  if (range) *range = k.range;
+  if (when) *when = k.when;
+  if (what) *what = k.what;
+  return TOR_OK;
+}
 
 int tor_last_render_timing(double out[5]) {
   if (!out) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_render_timing: out is NULL");
@@ -316,32 +330,32 @@ int tor_context_create(int32_t device, TorContext** out) {
     return fail_hip(e, "hipGetDeviceProperties");
   }
   ctx->num_cus = prop.multiProcessorCount;
-  if (const char* w = std::getenv("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
-  if (const char* l = std::getenv("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
-  if (const char* c = std::getenv("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
-  if (const char* c = std::getenv("TOR_BACK_SLOT")) ctx->back_slot = std::atoi(c);
-  if (const char* c = std::getenv("TOR_BACK_ACCEL")) ctx->back_accel = std::atoi(c) != 0;
-  if (const char* c = std::getenv("TOR_PROBE_SPP")) ctx->probe_spp = std::atoi(c) > 0 ? std::atoi(c) : 2;
-  if (const char* c = std::getenv("TOR_HOT_FRAC")) ctx->hot_frac = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_TAIL_FRAC")) ctx->tail_frac = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_PRIO_SHIFT")) ctx->prio_shift = std::atoi(c);
-  if (const char* c = std::getenv("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
-  if (const char* c = std::getenv("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
-  if (const char* c = std::getenv("TOR_MIGRATE")) ctx->mig_mode = std::atoi(c);
-  if (const char* c = std::getenv("TOR_SRV_FRAC")) ctx->srv_frac = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_SRV_PATIENCE_US")) ctx->srv_patience_us = std::atoi(c);
-  if (const char* c = std::getenv("TOR_SRV_MIN_FRAC")) ctx->srv_min_frac = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_PUSH_THETA")) ctx->push_theta = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_FLOOR_THETA")) ctx->floor_theta = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_CHAIN_THETA")) ctx->chain_theta = (float)std::atof(c);
-  if (const char* c = std::getenv("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
-  if (const char* c = std::getenv("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
-  if (const char* c = std::getenv("TOR_SCREEN")) ctx->screen = std::atoi(c) != 0;
-  if (const char* c = std::getenv("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
-  if (const char* c = std::getenv("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
-  if (const char* c = std::getenv("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
-  if (const char* b = std::getenv("TOR_BLOCKS_PER_CU"))
+  if (const char* w = tor::knob("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
+  if (const char* l = tor::knob("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
+  if (const char* c = tor::knob("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
+  if (const char* c = tor::knob("TOR_BACK_SLOT")) ctx->back_slot = std::atoi(c);
+  if (const char* c = tor::knob("TOR_BACK_ACCEL")) ctx->back_accel = std::atoi(c) != 0;
+  if (const char* c = tor::knob("TOR_PROBE_SPP")) ctx->probe_spp = std::atoi(c) > 0 ? std::atoi(c) : 2;
+  if (const char* c = tor::knob("TOR_HOT_FRAC")) ctx->hot_frac = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_TAIL_FRAC")) ctx->tail_frac = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_PRIO_SHIFT")) ctx->prio_shift = std::atoi(c);
+  if (const char* c = tor::knob("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
+  if (const char* c = tor::knob("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
+  if (const char* c = tor::knob("TOR_MIGRATE")) ctx->mig_mode = std::atoi(c);
+  if (const char* c = tor::knob("TOR_SRV_FRAC")) ctx->srv_frac = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_SRV_PATIENCE_US")) ctx->srv_patience_us = std::atoi(c);
+  if (const char* c = tor::knob("TOR_SRV_MIN_FRAC")) ctx->srv_min_frac = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_PUSH_THETA")) ctx->push_theta = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_FLOOR_THETA")) ctx->floor_theta = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_CHAIN_THETA")) ctx->chain_theta = (float)std::atof(c);
+  if (const char* c = tor::knob("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
+  if (const char* c = tor::knob("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
+  if (const char* c = tor::knob("TOR_SCREEN")) ctx->screen = std::atoi(c) != 0;
+  if (const char* c = tor::knob("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
+  if (const char* c = tor::knob("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
+  if (const char* c = tor::knob("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
+  if (const char* b = tor::knob("TOR_BLOCKS_PER_CU"))
     for (int s = 0; s < 2; ++s) ctx->max_blocks_per_cu[s][0] = ctx->max_blocks_per_cu[s][1] = std::atoi(b);
   e = ctx->counters.ensure(TorContext::kRing * TorContext::kSlotWords * sizeof(unsigned long long));
   if (e == hipSuccess) e = ctx->cam_ring.ensure(TorContext::kRing * sizeof(TorCamera));
@@ -607,7 +621,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
         q.bnd32 = (const float*)((const char*)q.bnd + bnd_host.size() * 8);
         if (hacc.two_level) bnd32_stage_floats = 8 * ((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad);
       }
-      const char* st = std::getenv("TOR_STAGE_LDS");
+      const char* st = tor::knob("TOR_STAGE_LDS");
       const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
       int& wg = stage_wg;
       wg = 0;
@@ -863,7 +877,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       p.mig_tail_rest = ctx->mig_tail_rest;
       // (read per launch, not per context: the drop-in's cached contexts outlive any one caller's settings)
       double stall_s = ctx->mig_stall_s;
-      if (const char* c = std::getenv("TOR_SRV_STALL_S")) stall_s = std::atof(c);
+      if (const char* c = tor::knob("TOR_SRV_STALL_S")) stall_s = std::atof(c);
       p.mig_stall_ticks = stall_s > 0.0 ? (unsigned long long)(stall_s * 1e8) + 2ull : (stall_s < 0.0 ? 1ull : 0ull);  // (< 0, a test setting: every waiting server gives up at its first look)
       ms.mig = p.mig;
       ms.lavg_scale = (float)spp / (float)ctx->probe_spp / ((float)blocks * (float)tor::kThreads);

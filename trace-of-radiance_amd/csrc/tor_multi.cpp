@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "tor_context.hpp"
+#include "tor_knobs.hpp"
 
 namespace tor {
 
@@ -116,7 +117,7 @@ int download_rows(TorContext* ctx, const void* d_src, int64_t n_rows, size_t row
   const size_t total = (size_t)n_rows * row_bytes;
   HIP_TRY(ctx->staging.ensure(total));
   size_t chunk_target = (size_t)2 << 20;  // measured on C2 (tools/host_canvas_tune.py): 8 threads x 2 MiB
-  if (const char* e = std::getenv("TOR_COPY_CHUNK_KB")) chunk_target = (size_t)std::atoll(e) << 10;
+  if (const char* e = tor::knob("TOR_COPY_CHUNK_KB")) chunk_target = (size_t)std::atoll(e) << 10;
   int64_t rows_per_chunk = (int64_t)(chunk_target / row_bytes);
   if (rows_per_chunk < 1) rows_per_chunk = 1;
   const int64_t n_chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
@@ -133,7 +134,7 @@ int download_rows(TorContext* ctx, const void* d_src, int64_t n_rows, size_t row
     HIP_TRY(hipEventRecord(ctx->chunk_events[(size_t)c], stream));
   }
   int n_workers = 8;
-  if (const char* e = std::getenv("TOR_COPY_THREADS")) n_workers = std::atoi(e);
+  if (const char* e = tor::knob("TOR_COPY_THREADS")) n_workers = std::atoi(e);
   if (n_workers < 1) n_workers = 1;
   if (n_workers > n_chunks) n_workers = (int)n_chunks;
   std::atomic<int> first_error{(int)hipSuccess};
@@ -194,7 +195,7 @@ thread_local std::string g_last_note;
 struct FaultInjection { bool rccl_init = false, rccl_xfer = false, peer = false, rccl_hang = false; };
 FaultInjection fault_injection() {
   FaultInjection f;
-  if (const char* e = std::getenv("TOR_FAULT_INJECT")) {
+  if (const char* e = tor::knob("TOR_FAULT_INJECT")) {
     f.rccl_init = std::strstr(e, "rccl_init") != nullptr;
     f.rccl_xfer = std::strstr(e, "rccl_xfer") != nullptr;
     f.peer = std::strstr(e, "peer") != nullptr;
@@ -314,7 +315,7 @@ int gather_host(const GatherJob& j) {
 // self-check (default 120 s).  TOR_FAULT_INJECT=rccl_hang replaces the transfer by a kernel that never ends on its own
 // (tests/test_gpu_round4.py).
 long env_ms(const char* name, long dflt) {
-  if (const char* e = std::getenv(name)) {
+  if (const char* e = tor::knob(name)) {
     char* endp = nullptr;
     const long v = std::strtol(e, &endp, 10);
     if (endp != e && v > 0) return v;
