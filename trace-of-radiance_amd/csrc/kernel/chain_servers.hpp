@@ -250,7 +250,8 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
         const unsigned long long m0 = ballot64(valid0 && ((slab_bit32(b32, bx0, by0, bz0) | wild) != 0u));
         const unsigned long long m1 = ballot64(valid1 && ((slab_bit32(b32, bx1, by1, bz1) | wild) != 0u));
         const unsigned c0 = (unsigned)__builtin_popcountll(m0), n_hit = c0 + (unsigned)__builtin_popcountll(m1);
-        const unsigned n_cand = n_always + 8u * n_hit;
+        const unsigned per_box = 8u * (unsigned)p.box_fanout;  // a box stands for box_fanout blocks of 8 consecutive cold slots
+        const unsigned n_cand = n_always + per_box * n_hit;
         // The boxes the ray can touch, compacted: lane r gets the index of the r-th such box -- every lane whose box was hit
         // pushes its box index to the lane of its rank (v_mbcnt + ds_permute; the others push to lane 63, which no rank below
         // 64 hits reaches).  A candidate lane then pulls `its` box with one ds_bpermute instead of walking the set bits
@@ -276,7 +277,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
         for (unsigned base = 0; base < n_cand; base += 64u) {
           const unsigned i = base + (unsigned)lane;
           int slot = -1;
-          const unsigned want = (i - n_always) >> 3;  // the (i - n_always)/8-th box the ray touches (garbage in lanes that have none)
+          const unsigned want = (i - n_always) / per_box;  // the box the ray touches that this candidate belongs to (garbage in lanes that have none)
           int box = 0;
           if (compact) {
             box = __builtin_amdgcn_ds_bpermute((int)((want & 63u) << 2), hit_list);
@@ -288,7 +289,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
               if (rank == want) box = 64 + (int)__builtin_ctzll(m);
           }
           if (i < n_always) slot = (int)i;
-          else if (i < n_cand) slot = p.spatial_base + 8 * box + (int)((i - n_always) & 7u);
+          else if (i < n_cand) slot = p.spatial_base + (int)per_box * box + (int)((i - n_always) % per_box);
 #if defined(TOR_SERVE_PROF) && TOR_SERVE_PROF >= 2
           {
             const unsigned long long pf_t = __builtin_readcyclecounter() + (slot == -77 ? 1ull : 0ull);

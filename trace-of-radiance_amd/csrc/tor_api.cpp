@@ -594,7 +594,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       use_layout(ctx->d_accel[v32].always);
       q.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
       q.spatial_base = (int)hacc.spatial_base;
-      q.n_super = (int)(((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) / tor::kPad);
+      q.n_super = (int)(tor::accel_boxes_padded(hacc) / tor::kPad);
+      q.box_fanout = hacc.fanout;
       q.two_level = hacc.two_level ? 1 : 0;
       q.shot = (const double*)ctx->d_accel[v32].hot.ptr;
       q.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;
@@ -619,7 +620,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
         // float32 boxes for the slab tests; on two-level scenes the lanes read the block boxes themselves: stage them
         q.sp_bmax = tor::block_bounds_f32(bnd_host, ctx->f32.origin, bnd32_host);
         q.bnd32 = (const float*)((const char*)q.bnd + bnd_host.size() * 8);
-        if (hacc.two_level) bnd32_stage_floats = 8 * ((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad);
+        if (hacc.two_level) bnd32_stage_floats = 8 * tor::accel_boxes_padded(hacc);
       }
       const char* st = tor::knob("TOR_STAGE_LDS");
       const size_t hard_cap = st ? (size_t)std::atoll(st) : (size_t)1 << 30;
@@ -686,7 +687,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     const int rc = configure_frame();
     if (rc != TOR_OK) return rc;
     const tor::HostAccel& ha = ctx->accel[1];
-    migrate = ctx->accel_built[1] && ha.available && ha.sp32 && !ha.two_level && (ha.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad <= 128 &&
+    migrate = ctx->accel_built[1] && ha.available && ha.sp32 && !ha.two_level && tor::accel_boxes_padded(ha) <= 128 &&
               use_accel && n_tiles > 1 && tor::integrate_variant_serves_chains(p, o.seeding) && resident_waves >= 8;
   }
   const bool split_applies = !migrate && o.pixel_kernel == TOR_PIXEL_KERNEL_AUTO && split_frac > 0.0f && ctx->lpt_min_spp > 0 && spp >= ctx->lpt_min_spp &&
@@ -762,7 +763,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   int blocks = (int)((waves + (tor::kThreads / 64) - 1) / (tor::kThreads / 64));
   if (blocks < 1) blocks = 1;
   p.screen = ctx->screen ? 1 : 0;
-  p.n_boxes = use_accel ? (int)((hacc.n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad) : 0;
+  p.n_boxes = use_accel ? (int)tor::accel_boxes_padded(hacc) : 0;
   p.mig = nullptr;
   if (migrate) blocks = (int)(resident_waves / (tor::kThreads / 64));  // the whole machine: waves without a tile are servers at once
   p.n_waves = (unsigned)(blocks * (tor::kThreads / 64));
@@ -1301,18 +1302,24 @@ int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_hi, int6
   std::vector<double> bnd;
   if (!tor::compute_block_bounds(acc, t_lo, t_hi, bnd)) return 0;
   const int64_t n_blocks = (int64_t)acc.n_blocks;
-  const int64_t n_bnd_p = (n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;
+  const int64_t n_bnd_p = (n_blocks + tor::kPad - 1) / tor::kPad * tor::kPad;          // (per block, as this view reports them)
+  const int64_t n_box_p = (int64_t)tor::accel_boxes_padded(acc), F = acc.fanout > 0 ? acc.fanout : 1;
   if (slot_cap < n_blocks * tor::kPad || box_cap < n_bnd_p) return TOR_ERR_INVALID_ARGUMENT;
   for (int64_t k = 0; k < n_blocks * tor::kPad; ++k) {
     int64_t orig = -1;
     if (acc.spatial[(size_t)k].valid) std::memcpy(&orig, &acc.cold[16 * (acc.spatial_base + (size_t)k) + 14], 8);
     slot_object[k] = orig;
   }
+  // (a culling box stands for `fanout` consecutive blocks: block b is reported with the box that covers it; a super box covers
+  // 8 boxes = 8 F blocks, reported per group of 8 BLOCKS as before -- the super box that covers the group's first block)
   for (int64_t b = 0; b < n_bnd_p; ++b)
-    for (int c = 0; c < 6; ++c) block_boxes[6 * b + c] = bnd[8 * (size_t)b + c];
+    for (int c = 0; c < 6; ++c) block_boxes[6 * b + c] = (b / F < n_box_p) ? bnd[8 * (size_t)(b / F) + c] : std::nan("");
   const int64_t n_super = n_bnd_p / tor::kPad;
   for (int64_t sidx = 0; sidx < n_super; ++sidx)
-    for (int c = 0; c < 6; ++c) super_boxes[6 * sidx + c] = bnd[8 * (size_t)(n_bnd_p + 1 + sidx) + c];
+    for (int c = 0; c < 6; ++c) {
+      const int64_t sb = (sidx * tor::kPad / F) / tor::kPad;  // super box of the group's first block
+      super_boxes[6 * sidx + c] = sb < n_box_p / tor::kPad ? bnd[8 * (size_t)(n_box_p + 1 + sb) + c] : std::nan("");
+    }
   if (two_level_out) *two_level_out = acc.two_level ? 1 : 0;
   return (int)n_blocks;
 }

@@ -51,6 +51,7 @@ struct KParams {
   int shot32_block_stride;  // floats per block of 4 pairs (4 * shot32_stride + padding)
   int shot32_lds_floats;  // > 0: copy that many floats of shot32 into LDS per workgroup
   float sp_mc0max, sp_dcmax;
+  int box_fanout;         // TOR_ACCEL_BLOCKS: blocks of 8 objects behind one culling box (tor_scene.hpp HostAccel::fanout); box b = blocks [b F, (b + 1) F)
   int two_level;          // the culling layout has super boxes (selects the BLOCKS = 2 kernel variants)
   const float* bnd32;     // float32 boxes (8 floats per record, same indices as bnd): {lo.x hi.x lo.y hi.y lo.z hi.z 0 0} - org
   float sp_bmax;          // max |box coordinate - org|

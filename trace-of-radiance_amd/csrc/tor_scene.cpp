@@ -453,10 +453,18 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   }
   std::stable_sort(keyed.begin(), keyed.end());
   out.n_blocks = (keyed.size() + kPad - 1) / kPad;
+  // box fan-out (tor_scene.hpp): default 2 -- 16 objects per culling box -- measured on random_scene (61 blocks) and the
+  // 1601-object animation frames (tools/fanout_sweep.py); TOR_BOX_FANOUT = 1 | 2 | 4 | 8 overrides
+  out.fanout = 2;
+  if (const char* e = tor::knob("TOR_BOX_FANOUT")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) out.fanout = v;
+  }
+  out.n_boxes = (out.n_blocks + (size_t)out.fanout - 1) / (size_t)out.fanout;
   out.spatial_base = out.always.n_sorted;
   out.cold = out.always.cold;
-  // cold slots for every bound slot of the (padded) bounds segment, all never-hit until filled
-  const size_t n_bnd_slots = (out.n_blocks + kPad - 1) / kPad * kPad;
+  // cold slots for every block behind the (padded) box segment, all never-hit until filled
+  const size_t n_bnd_slots = (out.n_boxes + kPad - 1) / kPad * kPad * (size_t)out.fanout;
   out.cold.resize(16 * (out.spatial_base + n_bnd_slots * kPad) + 16, 0.0);
   out.spatial.assign(out.n_blocks * kPad, HostAccel::Obj{});
   for (size_t k = 0; k < n_bnd_slots * kPad; ++k) out.cold[16 * (out.spatial_base + k) + 15] = -1.0;
@@ -492,8 +500,8 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
     o.t0 = c[7]; o.dt = c[8];
     o.abs_r = radii[(size_t)i];
   }
-  // the bounds segment (kind 3): records live in KParams.bnd, one per block, padded to 8
-  const size_t n_bnd_p = (out.n_blocks + kPad - 1) / kPad * kPad;
+  // the bounds segment (kind 3): records live in KParams.bnd, one per BOX (fanout blocks), padded to 8
+  const size_t n_bnd_p = (out.n_boxes + kPad - 1) / kPad * kPad;
   if (out.always.n_segs == 0) out.always.segs.clear();
   // few blocks: the wave-uniform loop tests the block boxes themselves (kind 3); otherwise it tests
   // the super boxes (kind 4: first record n_bnd_p + 1 of the bounds array) and the lanes descend
@@ -501,7 +509,7 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;
   size_t two_level_min = 96;
   if (const char* e = tor::knob("TOR_TWO_LEVEL_MIN")) two_level_min = (size_t)std::atoll(e);
-  out.two_level = out.n_blocks > two_level_min;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
+  out.two_level = out.n_boxes > two_level_min;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
   if (out.two_level)
     out.always.segs.insert(out.always.segs.end(), {4.0, (double)(n_bnd_p + 1), (double)n_super_p, 0.0, 0.0, 0.0, 0.0, 0.0});
   else
@@ -571,7 +579,8 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
 
 bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::vector<double>& bnd) {
   if (!std::isfinite(t_lo) || !std::isfinite(t_hi)) return false;
-  const size_t n_bnd_p = (acc.n_blocks + kPad - 1) / kPad * kPad;
+  const size_t F = (size_t)(acc.fanout > 0 ? acc.fanout : 1);
+  const size_t n_bnd_p = (acc.n_boxes + kPad - 1) / kPad * kPad;
   bnd.assign(8 * n_bnd_p + 16, 0.0);
   // padding / empty block: NaN bounds.  Every slab product is NaN, v_min/v_max drop NaN operands, so
   // t_in = 0 and t_out = NaN and `t_in <= t_out` is false.  (An inverted box would NOT do: the slab
@@ -579,11 +588,13 @@ bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::v
   const double qnan = std::nan("");
   for (size_t b = 0; b < n_bnd_p + 1; ++b)
     for (int a = 0; a < 6; ++a) bnd[8 * b + a] = qnan;
-  for (size_t b = 0; b < acc.n_blocks; ++b) {
+  for (size_t b = 0; b < acc.n_boxes; ++b) {  // box b: blocks [b F, (b + 1) F)
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     bool any = false;
-    for (int j = 0; j < kPad; ++j) {
-      const HostAccel::Obj& o = acc.spatial[b * kPad + j];
+    for (size_t j = 0; j < F * (size_t)kPad; ++j) {
+      const size_t slot = b * F * (size_t)kPad + j;
+      if (slot >= acc.spatial.size()) break;
+      const HostAccel::Obj& o = acc.spatial[slot];
       if (!o.valid) continue;
       // the centre moves linearly in t: the swept sphere lies in the hull of its two end positions
       const int ends = o.moving ? 2 : 1;

@@ -55,7 +55,13 @@ struct HostAccel {
   std::vector<double> groups;   // {time0, time1 - time0} per time group of the spatial objects
   size_t spatial_base = 0;      // first cold slot of the spatial objects (multiple of 8)
   size_t n_blocks = 0;
-  bool two_level = false;       // the uniform loop tests boxes around 8 blocks; lanes descend to the block boxes
+  // Box fan-out (round 4): a culling box of the wave-uniform loop covers `fanout` consecutive blocks (16 / 32 objects for
+  // fanout 2 / 4).  Every lane tests every box (14 float32 instructions each), the pooled resolve filters only the boxes a ray
+  // enters (8.5 instructions per object): with 8 objects per box the box tests were 4 x the filter work.  Blocks stay 8 objects
+  // (records, cold slots, masks); box b stands for blocks [b * fanout, (b + 1) * fanout).
+  int fanout = 1;
+  size_t n_boxes = 0;           // = ceil(n_blocks / fanout)
+  bool two_level = false;       // the uniform loop tests boxes around 8 boxes; lanes descend to those
   struct Obj { double c0[3], dc[3], t0, dt, abs_r; bool moving, valid; };
   std::vector<Obj> spatial;     // n_blocks * 8 entries (padding: valid = false)
   // TOR_ACCEL_F32 block expansion: float32 pair records of the spatial slots (tor_filter32.hpp), 4 pairs per
@@ -77,6 +83,7 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
 // boxes; then one slack record and the super boxes (one per 8 block boxes, again padded to 8).
 // Returns false when the time range is not finite (caller falls back to brute force).
 bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::vector<double>& bnd);
+inline size_t accel_boxes_padded(const HostAccel& acc) { return (acc.n_boxes + 7) / 8 * 8; }  // records of the kind-3 segment
 
 // The same boxes for the float32 slab test (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32): one record of 8 float32 per box,
 // same record indices as `bnd`, {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, 0, 0} relative to `origin`, lo rounded down
