@@ -1416,7 +1416,7 @@ int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const
     int word;
     if (mv) {
       const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, travel, cc0[1], f[i]);
-      word = tor::screen2_movy_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]), dcc[1], dcc[1] * dcc[1]);
+      word = tor::screen2_movy_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]), dcc[1]);
     } else if (variant == 1) {
       const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, 0.0, cc0[1], 0.0);
       word = tor::screen2_static_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]));

@@ -215,7 +215,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   for (const Seg64& sg : segs64) {
     const size_t cp = padded(sg.ids.size());
     (sg.kind == 0 ? n_stat_p : (sg.kind == 1 ? n_movy_p : n_mov_p)) += cp;
-    n_xrec += cp * (sg.xkind == 12 ? 6 : (sg.xkind != 0 ? 4 : 0));
+    n_xrec += cp * (sg.xkind != 0 ? 4 : 0);
   }
   std::vector<char> yonly32(groups32.size(), 0);
   size_t n32_slots = padded(statics32.size()), n32_floats = padded(statics32.size()) / 2 * 10;
@@ -266,7 +266,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
                                      sg.kind == 0 ? 0.0 : sg.t0, sg.kind == 0 ? 0.0 : sg.dt, up(reach), up(travel)});
     // second-form records of the screen (tor_screen.hpp): {xkind, first float64 of the records, common c0.y}
     out.xsegs.insert(out.xsegs.end(), {(double)sg.xkind, (double)x_off, sg.y, 0.0, 0.0, 0.0, 0.0, 0.0});
-    const size_t xs = sg.xkind == 12 ? 6 : (sg.xkind != 0 ? 4 : 0);
+    const size_t xs = sg.xkind != 0 ? 4 : 0;
     for (size_t k = 0; k < cnt_p && xs != 0; ++k) {  // padding: never a candidate (t'' = T - 1e300 < 0, disc'' < 0), except for a wild ray, which the exact test rejects
       double* x = &out.xrec[x_off + xs * k];
       x[sg.xkind == 10 ? 3 : 2] = 1e300;
@@ -290,9 +290,9 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
           m[3] = s.radius * s.radius;
           m[4] = dcy;
           if (sg.xkind == 12) {
-            double* x = &out.xrec[x_off + 6 * k];
+            double* x = &out.xrec[x_off + 4 * k];
             x[0] = s.center0.x; x[1] = s.center0.z; x[2] = screen2_Ky(s.center0.x, s.center0.z, s.radius * s.radius);
-            x[3] = dcy; x[4] = dcy * dcy; x[5] = 0.0;
+            x[3] = dcy;
           }
         } else {
           double* m = &out.mov[8 * (mov_rec + k)];
@@ -453,9 +453,12 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   }
   std::stable_sort(keyed.begin(), keyed.end());
   out.n_blocks = (keyed.size() + kPad - 1) / kPad;
-  // box fan-out (tor_scene.hpp): default 2 -- 16 objects per culling box -- measured on random_scene (61 blocks) and the
-  // 1601-object animation frames (tools/fanout_sweep.py); TOR_BOX_FANOUT = 1 | 2 | 4 | 8 overrides
-  out.fanout = 2;
+  // box fan-out (tor_scene.hpp): default 1.  Measured (tools/fanout_sweep.py, profiles/r4_fanout_sweep.txt): halving the box
+  // tests does NOT pay -- random_scene 56.4 / 59.0 / 73.0 / 115.3 ms and the 1601-object animation frame 38.3 / 40.7 / 50.7 /
+  // 108.1 ms for fan-out 1 / 2 / 4 / 8 (both accelerations, per-sample streams): a ray that skims the ground enters the union
+  // of two neighbouring blocks almost as often as it enters either, so the expansion work nearly doubles.  TOR_BOX_FANOUT keeps
+  // the experiment reproducible.
+  out.fanout = 1;
   if (const char* e = tor::knob("TOR_BOX_FANOUT")) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2 || v == 4 || v == 8) out.fanout = v;

@@ -16,7 +16,7 @@ struct HostLayout {
   std::vector<double> stat, mov, movy, segs, cold;
   // second form of the strict loop's FMA screen (tor_screen.hpp): per segment {xkind (0: none, 10 static, 11 static with a
   // common c0.y, 12 mover along y with a common c0.y), first float64 of its records in xrec, the common c0.y, 0...}; records
-  // {cx, cy, cz, K} | {cx, cz, K', 0} | {cx, cz, K', dcy, dcy^2, 0}, padded like the first form's
+  // {cx, cy, cz, K} | {cx, cz, K', 0} | {cx, cz, K', dcy}: 4 float64 each, padded like the first form's
   std::vector<double> xsegs, xrec;
   std::vector<float> hot32;  // TOR_ACCEL_F32 segments (kinds 5/6/7): packed pair records, see tor_kernels.hpp
   int n_segs = 0;
@@ -55,10 +55,10 @@ struct HostAccel {
   std::vector<double> groups;   // {time0, time1 - time0} per time group of the spatial objects
   size_t spatial_base = 0;      // first cold slot of the spatial objects (multiple of 8)
   size_t n_blocks = 0;
-  // Box fan-out (round 4): a culling box of the wave-uniform loop covers `fanout` consecutive blocks (16 / 32 objects for
-  // fanout 2 / 4).  Every lane tests every box (14 float32 instructions each), the pooled resolve filters only the boxes a ray
-  // enters (8.5 instructions per object): with 8 objects per box the box tests were 4 x the filter work.  Blocks stay 8 objects
-  // (records, cold slots, masks); box b stands for blocks [b * fanout, (b + 1) * fanout).
+  // Box fan-out (round 4 experiment, default 1 = off): a culling box of the wave-uniform loop covers `fanout` consecutive blocks
+  // (16 / 32 objects for fanout 2 / 4).  Every lane tests every box (14 float32 instructions each), the pooled resolve filters only
+  // the boxes a ray enters (8.5 instructions per object), so fewer, larger boxes looked cheaper on paper; measured, they are not
+  // (tor_scene.cpp build_accel).  Blocks stay 8 objects (records, cold slots, masks); box b stands for blocks [b * fanout, (b + 1) * fanout).
   int fanout = 1;
   size_t n_boxes = 0;           // = ceil(n_blocks / fanout)
   bool two_level = false;       // the uniform loop tests boxes around 8 boxes; lanes descend to those

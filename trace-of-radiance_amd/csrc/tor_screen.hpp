@@ -73,7 +73,7 @@ TOR_HD int screen_filter(double ocx, double ocy, double ocz, double dx, double d
 //   e_h: d~ carries a relative error <= 3.1 u per component (|d|^2 as the reference sums it: 2.5 u, sqrt, reciprocal, product);
 //        oy - Y, f d~y one rounding each; at most 7 fused operations in the two chains (per-ray part, per-object part):
 //        |e_h| <= (3.1 + 1 + 7) u sqrt(3) B + 7 u mu~ < 19.3 u B;
-//   e_t: K, K' (host: 3 roundings), dcy^2, f^2, 2 f (oy - Y) (<= 2 roundings), at most 9 fused operations over terms whose
+//   e_t: K, K' (host: 3 roundings), f^2, 2 f (oy - Y), g + nf2 dcy (<= 2 roundings each), at most 9 fused operations over terms whose
 //        magnitudes sum to <= B^2 + M~:  |e_t| < 16 u B^2.
 // With mu~ = 64 u B = 2^-47 B and M~ = 256 u B^2 = 2^-45 B^2:
 //   hb_ref < 0 (and D~ > -48 u B^2):  hb'' < 11 u B + 19.3 u B - 64 u B < 0; with m = mu~ - e_h >= 44.7 u B >= 2 H~,
@@ -148,10 +148,13 @@ TOR_HD int screen2_static_y(const ScreenSeg& s, double cx, double cz, double K) 
   const double t = fma_(s.o2x, cx, fma_(s.o2z, cz, s.T)) - K;
   return screen2_sign(hb, t);
 }
-// kind 12: record {cx, cz, K', dcy, K2 = dcy^2}
-TOR_HD int screen2_movy_y(const ScreenSeg& s, double cx, double cz, double K, double dcy, double K2) {
+// kind 12: record {cx, cz, K', dcy} -- 32 bytes like the static records (the whole second-form table of random_scene is then
+// 15.5 KB and fits the 16 KB scalar cache; with dcy^2 as a fifth field it was 21.7 KB and 4.5 % of the scalar loads missed).
+// 2 f (oy - Y) dcy - f^2 dcy^2 = (g + nf2 dcy) dcy: the same two instructions as with a stored dcy^2.
+TOR_HD int screen2_movy_y(const ScreenSeg& s, double cx, double cz, double K, double dcy) {
   const double hb = fma_(s.nfdy, dcy, fma_(-cx, s.dnx, fma_(-cz, s.dnz, s.P)));
-  const double t = fma_(s.g, dcy, fma_(s.nf2, K2, fma_(s.o2x, cx, fma_(s.o2z, cz, s.T)))) - K;
+  const double w = fma_(s.nf2, dcy, s.g);
+  const double t = fma_(w, dcy, fma_(s.o2x, cx, fma_(s.o2z, cz, s.T))) - K;
   return screen2_sign(hb, t);
 }
 // the host's side of the records (tor_scene.cpp build_layout; the self test)
