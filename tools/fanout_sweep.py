@@ -1,4 +1,4 @@
-"""Box fan-out of TOR_ACCEL_BLOCKS (TOR_BOX_FANOUT = blocks of 8 objects per culling box): step times of the accelerated modes on
+"""Box fan-out of TOR_ACCEL_BLOCKS (blocks of 8 objects per culling box; needs the library of commit c39354b, where TOR_BOX_FANOUT was read at upload): step times of the accelerated modes on
 configs[1] (random_scene, 485 objects) and on a configs[4] frame (1601 objects), every setting against the brute-force canvas."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -250,7 +250,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
         const unsigned long long m0 = ballot64(valid0 && ((slab_bit32(b32, bx0, by0, bz0) | wild) != 0u));
         const unsigned long long m1 = ballot64(valid1 && ((slab_bit32(b32, bx1, by1, bz1) | wild) != 0u));
         const unsigned c0 = (unsigned)__builtin_popcountll(m0), n_hit = c0 + (unsigned)__builtin_popcountll(m1);
-        const unsigned per_box = 8u * (unsigned)p.box_fanout;  // a box stands for box_fanout blocks of 8 consecutive cold slots
+        const unsigned per_box = 8u * (unsigned)kBoxFanout;  // a box stands for box_fanout blocks of 8 consecutive cold slots
         const unsigned n_cand = n_always + per_box * n_hit;
         // The boxes the ray can touch, compacted: lane r gets the index of the r-th such box -- every lane whose box was hit
         // pushes its box index to the lane of its rank (v_mbcnt + ds_permute; the others push to lane 63, which no rank below

@@ -595,7 +595,6 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       q.bnd = (const double*)((char*)ctx->bnd_ring.ptr + (size_t)slot * ctx->bnd_slot_bytes);  // filled below (async copy)
       q.spatial_base = (int)hacc.spatial_base;
       q.n_super = (int)(tor::accel_boxes_padded(hacc) / tor::kPad);
-      q.box_fanout = hacc.fanout;
       q.two_level = hacc.two_level ? 1 : 0;
       q.shot = (const double*)ctx->d_accel[v32].hot.ptr;
       q.sgrp = (const double*)ctx->d_accel[v32].grp.ptr;

@@ -13,6 +13,10 @@ namespace tor {
 
 constexpr int kThreads = 256;  // 4 waves per workgroup
 constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of this (= kBlock, the candidate-mask width)
+// TOR_ACCEL_BLOCKS: blocks of 8 objects behind ONE culling box (box b = blocks [b F, (b + 1) F)).  A compile-time constant: the
+// round-4 experiment ran it as a launch parameter (commit c39354b, profiles/r4_fanout_sweep.txt: 56.4 / 59.0 / 73.0 / 115.3 ms for
+// F = 1 / 2 / 4 / 8 on configs[1] with both accelerations) and the run-time loops alone cost the accelerated kernels 2-3 %.
+constexpr int kBoxFanout = 1;
 
 // Device scene (built by tor_scene_upload from the AoS HittableVariant list):
 //   stat : static spheres, 4 float64 each   {cx, cy, cz, radius^2}
@@ -51,7 +55,6 @@ struct KParams {
   int shot32_block_stride;  // floats per block of 4 pairs (4 * shot32_stride + padding)
   int shot32_lds_floats;  // > 0: copy that many floats of shot32 into LDS per workgroup
   float sp_mc0max, sp_dcmax;
-  int box_fanout;         // TOR_ACCEL_BLOCKS: blocks of 8 objects behind one culling box (tor_scene.hpp HostAccel::fanout); box b = blocks [b F, (b + 1) F)
   int two_level;          // the culling layout has super boxes (selects the BLOCKS = 2 kernel variants)
   const float* bnd32;     // float32 boxes (8 floats per record, same indices as bnd): {lo.x hi.x lo.y hi.y lo.z hi.z 0 0} - org
   float sp_bmax;          // max |box coordinate - org|

@@ -39,7 +39,6 @@ constexpr Knob kKnobs[] = {
     {"TOR_WAVES_PER_SIMD", "(from the launch shape)", "2 | 3", "context", "force the register-budget variant of integrate_kernel (256 / 168 VGPRs)"},
     {"TOR_STAGE_LDS", "(no cap)", "bytes, 0 = off", "call", "cap of the LDS staging of block records / boxes (TOR_ACCEL_BLOCKS)"},
     {"TOR_SCREEN", "1", "0 | 1", "context", "0: strict brute-force launches evaluate the reference's unfused discriminant for every object instead of the conservative FMA screen (same canvas)"},
-    {"TOR_BOX_FANOUT", "1", "1 | 2 | 4 | 8", "upload", "blocks of 8 objects per culling box of TOR_ACCEL_BLOCKS (every lane tests every box; only entered boxes are expanded); measured: 1 is fastest (profiles/r4_fanout_sweep.txt)"},
     {"TOR_TWO_LEVEL_MIN", "96", "blocks", "upload", "culling layouts with MORE than this many boxes get super boxes (two-level)"},
     // ---- TOR_SEED_PIXEL: kernel choice, cost probe, tile schedule ----
     {"TOR_COOP_MAX_PIXELS", "114688", ">= 0", "context", "frames up to this many pixels (per device) run one WAVE per pixel when neither hand-off nor split mode applies; 0 = never"},

@@ -453,16 +453,12 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   }
   std::stable_sort(keyed.begin(), keyed.end());
   out.n_blocks = (keyed.size() + kPad - 1) / kPad;
-  // box fan-out (tor_scene.hpp): default 1.  Measured (tools/fanout_sweep.py, profiles/r4_fanout_sweep.txt): halving the box
-  // tests does NOT pay -- random_scene 56.4 / 59.0 / 73.0 / 115.3 ms and the 1601-object animation frame 38.3 / 40.7 / 50.7 /
-  // 108.1 ms for fan-out 1 / 2 / 4 / 8 (both accelerations, per-sample streams): a ray that skims the ground enters the union
-  // of two neighbouring blocks almost as often as it enters either, so the expansion work nearly doubles.  TOR_BOX_FANOUT keeps
-  // the experiment reproducible.
-  out.fanout = 1;
-  if (const char* e = tor::knob("TOR_BOX_FANOUT")) {
-    const int v = std::atoi(e);
-    if (v == 1 || v == 2 || v == 4 || v == 8) out.fanout = v;
-  }
+  // box fan-out (tor_scene.hpp, tor_kernels.hpp kBoxFanout): 1.  Measured as a launch parameter in round 4 (commit c39354b,
+  // profiles/r4_fanout_sweep.txt): halving the box tests does NOT pay -- random_scene 56.4 / 59.0 / 73.0 / 115.3 ms and the
+  // 1601-object animation frame 38.3 / 40.7 / 50.7 / 108.1 ms for fan-out 1 / 2 / 4 / 8 (both accelerations, per-sample streams): a
+  // ray that skims the ground enters the union of two neighbouring blocks almost as often as it enters either, so the expansion
+  // work nearly doubles.  The host code stays general; the kernels take the constant.
+  out.fanout = kBoxFanout;
   out.n_boxes = (out.n_blocks + (size_t)out.fanout - 1) / (size_t)out.fanout;
   out.spatial_base = out.always.n_sorted;
   out.cold = out.always.cold;
