@@ -245,7 +245,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
         const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
         const double a = (ARITH != 1) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
         const RayF32 r32 = make_ray_f32(ox, oy, oz, dx, dy, dz, a_strict, p.org[0], p.org[1], p.org[2]);
-        const BoxRay32 b32 = make_box_ray32(r32, p.sp_bmax);
+        const BoxRay32 b32 = make_box_ray32(r32, p.sp_bmax, p.sp_hmin);
         const unsigned wild = r32.wild & 1u;  // a ray outside the float32 test's guarded ranges enters every box
         const unsigned long long m0 = ballot64(valid0 && ((slab_bit32(b32, bx0, by0, bz0) | wild) != 0u));
         const unsigned long long m1 = ballot64(valid1 && ((slab_bit32(b32, bx1, by1, bz1) | wild) != 0u));

@@ -617,7 +617,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       size_t bnd32_stage_floats = 0;
       if (q.shot32) {
         // float32 boxes for the slab tests; on two-level scenes the lanes read the block boxes themselves: stage them
-        q.sp_bmax = tor::block_bounds_f32(bnd_host, ctx->f32.origin, bnd32_host);
+        q.sp_bmax = tor::block_bounds_f32(bnd_host, ctx->f32.origin, bnd32_host, &q.sp_hmin);
         q.bnd32 = (const float*)((const char*)q.bnd + bnd_host.size() * 8);
         if (hacc.two_level) bnd32_stage_floats = 8 * tor::accel_boxes_padded(hacc);
       }
@@ -1497,13 +1497,14 @@ int tor_selftest_slab32_host(int64_t n, const double* o, const double* d, const 
   for (int64_t i = 0; i < n; ++i)
     for (int k = 0; k < 3; ++k) { bnd[8 * i + k] = lo[3 * i + k]; bnd[8 * i + 3 + k] = hi[3 * i + k]; }
   std::vector<float> bnd32;
-  const float bmax = tor::block_bounds_f32(bnd, origin, bnd32);
+  float hmin = 0.0f;
+  const float bmax = tor::block_bounds_f32(bnd, origin, bnd32, &hmin);
   using tor::f2v;
   for (int64_t i = 0; i < n; ++i) {
     const double* oo = o + 3 * i; const double* dd = d + 3 * i;
     const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
     const tor::RayF32 r = tor::make_ray_f32(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a, origin[0], origin[1], origin[2]);
-    const tor::BoxRay32 b = tor::make_box_ray32(r, bmax);
+    const tor::BoxRay32 b = tor::make_box_ray32(r, bmax, hmin);
     const float* rec = &bnd32[8 * (size_t)i];
     keep[i] = (int32_t)(tor::slab_bit32(b, (f2v){rec[0], rec[1]}, (f2v){rec[2], rec[3]}, (f2v){rec[4], rec[5]}) | (r.wild & 1u));
     const double ix = 1.0 / dd[0], iy = 1.0 / dd[1], iz = 1.0 / dd[2];

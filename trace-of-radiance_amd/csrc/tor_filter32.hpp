@@ -132,54 +132,57 @@ TOR_HD unsigned filter_pair32(const RayF32& r, const SegF32& s, f2v ocx, f2v ocy
 }
 
 // ---- float32 slab test for the culling boxes (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32) ---------------------------------
-// Box records hold {lo, hi} per axis relative to P, lo rounded down and hi rounded up from the float64 box (which is
-// itself inflated by 1e-6 relative around the swept spheres).  The ray side: o^ = fl(o - P) is off by <= u |o-P|, and
-// fl((lo, hi) - o^) adds <= u (|lo| + |o^|): both are absorbed by testing the box inflated by e = 3 u (|o-P| + max|box|)
-// on every side, folded into the per-lane addend (-o^ - e, -o^ + e).  What remains is relative: the entry / exit
-// parameters carry <= 2.5 u (rounding of d, of 1/d and of the product).  A relative error delta of t = (b - o)/d is the
-// error of a plane moved by |delta| |b - o| <= 2.6 u (|o-P| + max|box|), so it is paid in the same coin: the inflation is
-// e = 6 u (|o-P| + max|box|) (3 u + 2.6 u, rounded up) and the test is the plain `t_in <= t_out` -- one instruction per box
-// less than the relative slack `t_out (1 + 2^-20)` of rounds 1-2 cost.  NaN (0 * inf on an axis the ray is parallel to, or
-// a NaN padding box) is dropped by min/max exactly as in the float64 test.
+// Box records hold {centre, half-extent} per axis relative to P: c = fl32 of the float64 box's midpoint, h rounded UP so that
+// [c - h, c + h] contains the float64 box (which is itself inflated by 1e-6 relative around the swept spheres).  Round 4: the
+// centre form.  The entry / exit parameters of an axis are
+//     u = c (1/d^) + (-o^ (1/d^))           one v_fma_f32 (2 cycles; the second product is formed once per ray)
+//     (t_near, t_far) = u -+ h |1/d^|       one v_pk_fma_f32 against the ray's (-H, +H)
+// with NO per-lane min / max to sort the two planes by the sign of d (the {lo, hi} form needed a packed fma + v_min + v_max:
+// 8 cycles per axis instead of 6; 28 instead of 34 cycles per box).
+// Errors, all expressed as the displacement of a box plane (a relative error delta of t = (b - o)/d moves the plane by
+// |delta| |b - o| <= |delta| (|o-P| + max|box|)), u = 2^-24:  o^ = fl(o - P): u |o-P|;  d^ and 1/d^: 2 u (|o-P| + max|box|);
+// the per-ray product -o^ (1/d^): u |o-P|;  the rounding of u: u (|o-P| + max|box|);  the rounding of t and of H: u (|o-P| + 2 max|box|).
+// Together < 8 u (|o-P| + max|box|) =: e.  The test runs on every box inflated by e on every side, and since every half-extent is at
+// least h_min (host: the smallest one over the valid boxes), scaling the ray's H by (1 + e / h_min) inflates every box by >= e
+// without an instruction per box: (h + e) H <= h H (1 + e / h_min).  At random_scene's scale e / h_min ~ 1e-5; a camera a hundred
+// scene sizes away still only widens the boxes by a per mille.  The test itself is the plain `t_in <= t_out`.  NaN (0 * inf on an
+// axis the ray is parallel to while the origin sits in the slab's mid-plane, or a NaN padding box) is dropped by min / max exactly
+// as in the float64 test: that axis stops constraining, a padding box is never entered.
 struct BoxRay32 {
-  f2v ax, ay, az;  // (-o^ - e, -o^ + e) / d^ per axis (the quotient is formed per ray, see slab_bit32)
-  f2v ix, iy, iz;  // 1/d^ per axis, both halves
+  float ix, iy, iz;  // 1/d^ per axis (0 for an axis the ray is parallel to)
+  float ax, ay, az;  // -o^ / d^ (0 for such an axis)
+  f2v hx, hy, hz;    // (-H, +H), H = |1/d^| (1 + e / h_min) rounded up (+inf for such an axis)
 };
 
-TOR_HD BoxRay32 make_box_ray32(const RayF32& r, float bmax) {
+TOR_HD BoxRay32 make_box_ray32(const RayF32& r, float bmax, float hmin) {
   BoxRay32 b;
-  const float e = 6.0f * kU32 * (r.ro + bmax);
-  // An axis the ray is (nearly) parallel to -- |1/d^| = inf or so large that the per-ray product could overflow --
-  // must not constrain: in the fused form box * inf + (-o^) * inf is inf - inf = NaN exactly when the origin lies
-  // between the planes, and max(-inf, NaN) would then report "leaves before it enters".  Such an axis gets
-  // 1/d^ := 0 and the addend (-inf, +inf): t = (-inf, +inf), no constraint (a NaN padding box still yields NaN).
+  const float e = 8.0f * kU32 * (r.ro + bmax);
+  const float grow = (1.0f + e / hmin) * (1.0f + 4.0f * kU32);  // (h_min = 0: inf -> every box is entered)
+  // An axis the ray is (nearly) parallel to -- |1/d^| = inf or so large that the products could overflow -- must not
+  // constrain: it gets 1/d^ := 0, addend 0 and H := +inf, i.e. t = (-inf, +inf) for h > 0 (and NaN, dropped, for h = 0).
   const float inf = __builtin_inff();
-  auto axis = [&](float o, float d, f2v& a, f2v& i) {
+  auto axis = [&](float o, float d, float& i, float& a, f2v& h) {
     const float id = 1.0f / d;
     const bool open = !(__builtin_fabsf(id) <= 0x1p100f);  // inf, NaN or huge
-    i = splat2(open ? 0.0f : id);
-    a = open ? (f2v){-inf, inf} : (f2v){(-o - e) * id, (-o + e) * id};
+    i = open ? 0.0f : id;
+    a = open ? 0.0f : -o * id;
+    const float H = open ? inf : __builtin_fabsf(id) * grow;
+    h = (f2v){-H, H};
   };
-  axis(r.ox, r.dx, b.ax, b.ix);
-  axis(r.oy, r.dy, b.ay, b.iy);
-  axis(r.oz, r.dz, b.az, b.iz);
+  axis(r.ox, r.dx, b.ix, b.ax, b.hx);
+  axis(r.oy, r.dy, b.iy, b.ay, b.hy);
+  axis(r.oz, r.dz, b.iz, b.az, b.hz);
   return b;
 }
 
-// 1: the ray may touch the box {bx = (lo.x, hi.x), by, bz}; 0: it cannot.
+// 1: the ray may touch the box {bx = (c.x, h.x), by, bz}; 0: it cannot.
 TOR_HD unsigned slab_bit32(const BoxRay32& b, f2v bx, f2v by, f2v bz) {
-  // t = (box - o^ -+ e) / d^ as ONE fused multiply-add per axis: box * (1/d^) + ((-o^ -+ e) * (1/d^)), the second product
-  // formed once per ray.  Against the two-step form this moves one rounding: the per-ray product carries u |o^ +- e| |1/d^|,
-  // which is a box-coordinate error of u (|o-P| + e) -- inside the first 3 u (|o-P| + max|box|) of the inflation, whose budget
-  // so far only spent u |o-P| (rounding of o^) + u (|box| + |o^|) (the subtraction, now exact inside the fma).  With
-  // d^ = 0 an axis gives inf - inf = NaN more often than before (whenever box and origin terms differ in sign); NaN is
-  // dropped by min/max, i.e. that axis stops constraining: conservative.
-  const f2v tx = fma2(bx, b.ix, b.ax), ty = fma2(by, b.iy, b.ay), tz = fma2(bz, b.iz, b.az);
+  const float cx = bx.x, hx = bx.y, cy = by.x, hy = by.y, cz = bz.x, hz = bz.y;
+  const float ux = __builtin_fmaf(cx, b.ix, b.ax), uy = __builtin_fmaf(cy, b.iy, b.ay), uz = __builtin_fmaf(cz, b.iz, b.az);
+  const f2v tx = fma2(splat2(hx), b.hx, splat2(ux)), ty = fma2(splat2(hy), b.hy, splat2(uy)), tz = fma2(splat2(hz), b.hz, splat2(uz));
   const float tx0 = tx.x, tx1 = tx.y, ty0 = ty.x, ty1 = ty.y, tz0 = tz.x, tz1 = tz.y;
-  const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)),
-                                     __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
-  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)),
-                                      __builtin_fmaxf(tz0, tz1));
+  const float t_in = __builtin_fmaxf(__builtin_fmaxf(tx0, ty0), __builtin_fmaxf(tz0, 0.0f));
+  const float t_out = __builtin_fminf(__builtin_fminf(tx1, ty1), tz1);
   return (t_in <= t_out) ? 1u : 0u;
 }
 

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 
       BoxRay32 b32{};
       const bool boxes32 = F32 && BLOCKS && p.bnd32 != nullptr;
-      if (boxes32) b32 = make_box_ray32(r32, p.sp_bmax);
+      if (boxes32) b32 = make_box_ray32(r32, p.sp_bmax, p.sp_hmin);
 
       // TOR_ACCEL_F32 block expansion: the spatial movers share one time group
       SegF32 sp32{};

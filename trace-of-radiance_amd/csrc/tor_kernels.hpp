@@ -56,8 +56,9 @@ struct KParams {
   int shot32_lds_floats;  // > 0: copy that many floats of shot32 into LDS per workgroup
   float sp_mc0max, sp_dcmax;
   int two_level;          // the culling layout has super boxes (selects the BLOCKS = 2 kernel variants)
-  const float* bnd32;     // float32 boxes (8 floats per record, same indices as bnd): {lo.x hi.x lo.y hi.y lo.z hi.z 0 0} - org
+  const float* bnd32;     // float32 boxes (8 floats per record, same indices as bnd): {c.x h.x c.y h.y c.z h.z 0 0}, centre - org and half-extent
   float sp_bmax;          // max |box coordinate - org|
+  float sp_hmin;          // smallest half-extent of a culling box (tor_filter32.hpp make_box_ray32)
   int bnd32_lds_floats;   // > 0: the block boxes (two-level scenes: the per-lane descent reads them) are staged in LDS too
   double sp_t0, sp_dt;    // the spatial movers' time group
   int spatial_base;    // first cold slot of the spatial blocks: block b owns cold[spatial_base + 8b .. +8)

@@ -640,10 +640,10 @@ bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::v
   return true;
 }
 
-float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], std::vector<float>& bnd32) {
+float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], std::vector<float>& bnd32, float* hmin_out) {
   const size_t n = bnd.size() / 8;
   bnd32.assign(8 * n, 0.0f);
-  double bmax = 0.0;
+  double bmax = 0.0, hmin = INFINITY;
   for (size_t b = 0; b < n; ++b) {
     const double* c = &bnd[8 * b];
     float* r = &bnd32[8 * b];
@@ -652,15 +652,20 @@ float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], s
       continue;
     }
     for (int ax = 0; ax < 3; ++ax) {
+      // {centre, half-extent}: the float32 interval [fc - fh, fc + fh] (exact arithmetic on the float32 values) contains [lo, hi]
       const double lo = c[ax] - origin[ax], hi = c[3 + ax] - origin[ax];
-      float flo = (float)lo, fhi = (float)hi;
-      if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
-      if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
-      r[2 * ax] = flo;
-      r[2 * ax + 1] = fhi;
-      bmax = std::max(bmax, std::max(std::fabs((double)flo), std::fabs((double)fhi)));
+      const float fc = (float)(0.5 * (lo + hi));
+      const double need = std::max((double)fc - lo, hi - (double)fc);
+      float fh = (float)need;
+      if ((double)fh < need) fh = std::nextafterf(fh, INFINITY);
+      fh = std::nextafterf(fh, INFINITY);
+      r[2 * ax] = fc;
+      r[2 * ax + 1] = fh;
+      bmax = std::max(bmax, std::fabs((double)fc) + (double)fh);
+      hmin = std::min(hmin, (double)fh);
     }
   }
+  if (hmin_out) *hmin_out = std::isfinite(hmin) ? (float)hmin : 0.0f;   // (fh is a float32 already: exact)
   return f32_round_up(bmax);
 }
 

@@ -86,8 +86,9 @@ bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::v
 inline size_t accel_boxes_padded(const HostAccel& acc) { return (acc.n_boxes + 7) / 8 * 8; }  // records of the kind-3 segment
 
 // The same boxes for the float32 slab test (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32): one record of 8 float32 per box,
-// same record indices as `bnd`, {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, 0, 0} relative to `origin`, lo rounded down
-// and hi rounded up (NaN records stay NaN).  Returns max |coordinate| over the valid boxes, rounded up.
-float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], std::vector<float>& bnd32);
+// same record indices as `bnd`, {c.x, h.x, c.y, h.y, c.z, h.z, 0, 0} relative to `origin` -- centre and half-extent, the
+// half-extent rounded up so that the float32 box contains the float64 one (NaN records stay NaN).  Returns max |coordinate| over the
+// valid boxes, rounded up; *hmin_out = the smallest half-extent (tor_filter32.hpp: the ray-side inflation is relative to it).
+float block_bounds_f32(const std::vector<double>& bnd, const double origin[3], std::vector<float>& bnd32, float* hmin_out);
 
 }  // namespace tor
