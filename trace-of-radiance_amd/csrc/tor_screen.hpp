@@ -91,11 +91,22 @@ struct ScreenRay {     // per ray and closest-hit query
   double ox, oy, oz;
   bool wild;
 };
-struct ScreenSeg {     // per ray and segment
-  double dnx, dny, dnz;  // d~ (0 for a wild ray)
-  double o2x, o2y, o2z;  // 2 o (0 for a wild ray)
-  double P, T;           // kind 10: o.d~ - mu~ and M~ - |o|^2;  kinds 11 / 12: the same with oy - Y for oy
-  double nfdy, g, nf2;   // kind 12: -f d~y, 2 f (oy - Y), -f^2
+// ONE sign per test.  keep = (hb'' < 0 or t'' >= 0) and disc'' >= 0 is the sign of a single value:
+//     q = t'' + max(-hb'', 0)^2        hb'' >= 0: q = t'' (and t'' >= 0 implies disc'' = hb''^2 + t'' >= 0);  hb'' < 0: q = disc''
+// and max(., 0) is the CLAMP modifier of the instruction that ends the hb chain -- free -- provided the value stays below the clamp's
+// upper bound 1.  So the segment's per-ray factors carry a power of two sigma <= 1 / (2 B) (|hb''| <= B (1 + 2^-40): the clamp never
+// saturates): the hb chain is evaluated as Nh = clamp(sigma (c.d~ - P)) = sigma max(-hb'', 0), the t chain as -sigma^2 t'' (the `- K`
+// becomes one more fma, same count), and q' = fma(-Nh, Nh, -sigma^2 t'') = -sigma^2 q.  Scaling by powers of two is exact, so the
+// decision is the three-sign decision above bit for bit except where q is exactly 0, which the proof never needs (every object
+// it keeps has q > 0 strictly).  The v_bitop3_b32 is gone: 7 / 9 / 10 instructions per common-height static / static / mover
+// instead of 8 / 10 / 11, one of them (the v_alignbit into the mask) not float64.
+struct ScreenSeg {     // per ray and segment (s = sigma)
+  double hx, hy, hz;     // s d~ (0 for a wild ray)
+  double Pn;             // s (mu~ - o.d~)            kinds 11 / 12: with oy - Y for oy
+  double a2x, a2y, a2z;  // -s^2 2 o (0 for a wild ray)
+  double Tn;             // -s^2 (M~ - |o|^2); -inf for a wild ray: everything is kept
+  double ks;             // s^2
+  double fdy, gn, f2n;   // kind 12: s f d~y, -s^2 2 f (oy - Y), s^2 f^2
 };
 TOR_HD ScreenRay screen2_ray(double ox, double oy, double oz, double dx, double dy, double dz, double a_strict) {
   ScreenRay r;
@@ -106,6 +117,18 @@ TOR_HD ScreenRay screen2_ray(double ox, double oy, double oz, double dx, double 
   r.wild = !(a_strict >= 0x1p-900 && a_strict <= 0x1p900);
   return r;
 }
+// clamp(x) to [0, 1] with NaN -> 0: what the hardware's clamp modifier does (compute kernels run with DX10_CLAMP = 1)
+TOR_HD double clamp01(double x) { return x > 0.0 ? (x < 1.0 ? x : 1.0) : 0.0; }
+// fma(a, b, c) clamped to [0, 1]; a is wave-uniform (a scalar register on the device)
+TOR_HD double fma_clamp_s(double a_uniform, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(a_uniform), "v"(b), "v"(c));
+  return r;
+#else
+  return clamp01(fma_(a_uniform, b, c));
+#endif
+}
 // reach, travel: segs[6], segs[7]; y_rel: 0 for the general static form (kind 10), else the segment's common c0.y (kinds 11, 12);
 // f: the segment's time fraction (kind 12), else 0
 TOR_HD ScreenSeg screen2_seg(const ScreenRay& r, double reach, double travel, double y_rel, double f) {
@@ -114,48 +137,51 @@ TOR_HD ScreenSeg screen2_seg(const ScreenRay& r, double reach, double travel, do
   const double mu = B * 0x1p-47;
   const double M = (B * B) * 0x1p-45;
   const bool wild = r.wild || !(M < __builtin_inf());
+  // sigma = 2^-(e + 2) for B in [2^e, 2^(e+1)): sigma B < 1/2.  (B = 0 or denormal: 2^1020; harmless, every product below is 0 or tiny)
+  uint64_t e = (double_to_bits(B) >> 52) & 0x7ffu;
+  if (e < 3u) e = 3u;
+  if (e > 0x7fbu) e = 0x7fbu;
+  const double sg = bits_to_double((uint64_t)(0x7fcu - e) << 52), sg2 = sg * sg;
   const double oy = r.oy - y_rel;
-  s.dnx = wild ? 0.0 : r.dnx; s.dny = wild ? 0.0 : r.dny; s.dnz = wild ? 0.0 : r.dnz;
-  s.o2x = wild ? 0.0 : r.ox + r.ox; s.o2y = wild ? 0.0 : oy + oy; s.o2z = wild ? 0.0 : r.oz + r.oz;
-  const double P = fma_(oy, s.dny, fma_(r.oz, s.dnz, r.ox * s.dnx)) - mu;
+  const double dnx = wild ? 0.0 : r.dnx, dny = wild ? 0.0 : r.dny, dnz = wild ? 0.0 : r.dnz;
+  s.hx = sg * dnx; s.hy = sg * dny; s.hz = sg * dnz;
+  const double P = fma_(oy, dny, fma_(r.oz, dnz, r.ox * dnx)) - mu;
   const double Q = fma_(oy, oy, fma_(r.oz, r.oz, r.ox * r.ox));
-  s.P = wild ? -1.0 : P;
-  s.T = wild ? __builtin_inf() : M - Q;
-  s.nfdy = -(f * s.dny);
-  s.g = f * s.o2y;
-  s.nf2 = wild ? 0.0 : -(f * f);
+  s.Pn = wild ? 0.0 : -(sg * P);
+  s.Tn = wild ? -__builtin_inf() : -(sg2 * (M - Q));
+  const double n2 = wild ? 0.0 : -(sg2 + sg2);
+  s.a2x = n2 * r.ox; s.a2y = n2 * oy; s.a2z = n2 * r.oz;
+  s.ks = sg2;
+  s.fdy = f * s.hy;
+  s.gn = f * s.a2y;
+  s.f2n = wild ? 0.0 : sg2 * (f * f);
   return s;
 }
-// the three per-object tests; the returned word's SIGN BIT is the decision (set = keep), as screen_filter's
-TOR_HD int screen2_sign(double hb, double t) {
-  const double disc = fma_(hb, hb, t);
-  const unsigned h = (unsigned)(double_to_bits(hb) >> 32), y = (unsigned)(double_to_bits(t) >> 32), z = (unsigned)(double_to_bits(disc) >> 32);
-#if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
-  return (int)__builtin_amdgcn_bitop3_b32(h, y, z, 0x51);
-#else
-  return (int)((h | ~y) & ~z);
-#endif
+// the per-object tests; the returned word's SIGN BIT is the decision (set = keep), as screen_filter's
+TOR_HD int screen2_word(double nh, double tn) {
+  const double q = fma_(-nh, nh, tn);
+  return (int)(unsigned)(double_to_bits(q) >> 32);
 }
 // kind 10: record {cx, cy, cz, K = |c|^2 - r^2}
 TOR_HD int screen2_static(const ScreenSeg& s, double cx, double cy, double cz, double K) {
-  const double hb = fma_(-cx, s.dnx, fma_(-cy, s.dny, fma_(-cz, s.dnz, s.P)));
-  const double t = fma_(s.o2x, cx, fma_(s.o2y, cy, fma_(s.o2z, cz, s.T))) - K;
-  return screen2_sign(hb, t);
+  const double nh = fma_clamp_s(cx, s.hx, fma_(cy, s.hy, fma_(cz, s.hz, s.Pn)));
+  const double tn = fma_(s.ks, K, fma_(s.a2x, cx, fma_(s.a2y, cy, fma_(s.a2z, cz, s.Tn))));
+  return screen2_word(nh, tn);
 }
 // kind 11: record {cx, cz, K' = cx^2 + cz^2 - r^2}
 TOR_HD int screen2_static_y(const ScreenSeg& s, double cx, double cz, double K) {
-  const double hb = fma_(-cx, s.dnx, fma_(-cz, s.dnz, s.P));
-  const double t = fma_(s.o2x, cx, fma_(s.o2z, cz, s.T)) - K;
-  return screen2_sign(hb, t);
+  const double nh = fma_clamp_s(cx, s.hx, fma_(cz, s.hz, s.Pn));
+  const double tn = fma_(s.ks, K, fma_(s.a2x, cx, fma_(s.a2z, cz, s.Tn)));
+  return screen2_word(nh, tn);
 }
 // kind 12: record {cx, cz, K', dcy} -- 32 bytes like the static records (the whole second-form table of random_scene is then
 // 15.5 KB and fits the 16 KB scalar cache; with dcy^2 as a fifth field it was 21.7 KB and 4.5 % of the scalar loads missed).
 // 2 f (oy - Y) dcy - f^2 dcy^2 = (g + nf2 dcy) dcy: the same two instructions as with a stored dcy^2.
 TOR_HD int screen2_movy_y(const ScreenSeg& s, double cx, double cz, double K, double dcy) {
-  const double hb = fma_(s.nfdy, dcy, fma_(-cx, s.dnx, fma_(-cz, s.dnz, s.P)));
-  const double w = fma_(s.nf2, dcy, s.g);
-  const double t = fma_(w, dcy, fma_(s.o2x, cx, fma_(s.o2z, cz, s.T))) - K;
-  return screen2_sign(hb, t);
+  const double nh = fma_clamp_s(dcy, s.fdy, fma_(cx, s.hx, fma_(cz, s.hz, s.Pn)));
+  const double w = fma_(s.f2n, dcy, s.gn);
+  const double tn = fma_(s.ks, K, fma_(w, dcy, fma_(s.a2x, cx, fma_(s.a2z, cz, s.Tn))));
+  return screen2_word(nh, tn);
 }
 // the host's side of the records (tor_scene.cpp build_layout; the self test)
 TOR_HD double screen2_K(double cx, double cy, double cz, double r2) { return ((cx * cx + cy * cy) + cz * cz) - r2; }
