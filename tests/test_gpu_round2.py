@@ -448,11 +448,12 @@ def test_pixel_schedule_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera
                      for r in rows])
     knobs = [
         {},
-        {"TOR_TAIL_FRAC": "0.7", "TOR_HOT_FRAC": "0.02", "TOR_PRIO_SHIFT": "6"},
+        {"TOR_BACK_SLOT": "2", "TOR_TAIL_FRAC": "0.7", "TOR_HOT_FRAC": "0.02", "TOR_PRIO_SHIFT": "6"},
+        {"TOR_BACK_SLOT": "2"},                                # the two-region schedule as rounds 2-3 ran it by default
         {"TOR_BACK_SLOT": "1", "TOR_TAIL_FRAC": "0.05"},
         {"TOR_BACK_SLOT": "-1", "TOR_TAIL_FRAC": "0.3"},   # every wave takes itself for a slow-slot wave: region A must still be rendered
         {"TOR_BACK_SLOT": "0", "TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0"},
-        {"TOR_BACK_ACCEL": "1", "TOR_TAIL_FRAC": "0.5"},
+        {"TOR_BACK_SLOT": "2", "TOR_BACK_ACCEL": "1", "TOR_TAIL_FRAC": "0.5"},
         {"TOR_LPT_MIN_SPP": "0"},
         {"TOR_BLOCKS_PER_CU": "2", "TOR_WAVES_PER_SIMD": "2"},
     ]

@@ -119,7 +119,11 @@ struct TorContext {
   tor::DeviceBuffer counters;                      // kRing x 8 u64: [0] work counter, [1..4] stats, [5] probe counter
   tor::DeviceBuffer tile_order[kRing];  // SEED_PIXEL schedule: the tile order a launch reads
   tor::DeviceBuffer probe_buf;          // ... and what the sort is made from: per-pixel probe counts, per-tile key and work
-  int back_slot = 2;    // SEED_PIXEL: wave slots >= this take tiles from the cheap end (0 = none; TOR_BACK_SLOT)
+  // SEED_PIXEL: wave slots >= this take tiles from the cheap end (0 = none; TOR_BACK_SLOT).  Round 4: 0.  The two-region schedule
+  // was worth 5-10 % to the float64 brute force of rounds 2-3 (slot 2 of a SIMD got a fifth of slot 0's service); with the round-4
+  // object loop it COSTS 4-7 % (profiles/r4_pixel_brute_knobs.txt: 1777 -> 1851 Msamples/s at configs[2], 1677 -> 1795 at
+  // configs[1] with it off; the cost-ordered tile list itself stays essential: 1059 without it).
+  int back_slot = 0;
   float hot_frac = 0.4f;   // a pixel chain is hot (arbiter priority 3) from this share of an average wave's iterations on (TOR_HOT_FRAC; 0 = off)
   float tail_frac = 0.2f;  // share of the lane kernel's probed work in region B of its schedule (TOR_TAIL_FRAC)
   int probe_spp = 2;            // samples per pixel of the cost probe (TOR_PROBE_SPP: debugging the schedule)

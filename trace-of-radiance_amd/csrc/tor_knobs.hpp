@@ -46,7 +46,7 @@ constexpr Knob kKnobs[] = {
     {"TOR_PROBE_SPP", "2", ">= 1", "context", "samples per pixel of the cost probe"},
     {"TOR_PROBE_ACCEL", "1", "0 | 1", "context", "1: the probe always walks the culling layout (it only counts queries); 0: the frame's layout"},
     {"TOR_KEY_MODE", "1", "0 | 1", "context", "tile sort key: 0 longest probed pixel, 1 certain long chains first, then the tile's sum"},
-    {"TOR_BACK_SLOT", "2", "-1 | 0..", "context", "waves in hardware slots >= this take tiles from the cheap end only; 0 = none, -1 = every wave (test setting)"},
+    {"TOR_BACK_SLOT", "0", "-1 | 0..", "context", "two-region tile schedule of the brute force: waves in hardware slots >= this take tiles from the cheap end only; 0 = none (default since round 4: it costs the new object loop 4-7 %), 2 = rounds 2-3, -1 = every wave (test setting)"},
     {"TOR_BACK_ACCEL", "0", "0 | 1", "context", "two schedule regions with an exact acceleration too"},
     {"TOR_TAIL_FRAC", "0.2", "0..1", "context", "share of the probed work in region B of the schedule"},
     {"TOR_HOT_FRAC", "0.4", ">= 0", "context", "a pixel chain is HOT (arbiter priority 3) from this share of an average wave's iterations; 0 = off"},
