@@ -374,7 +374,8 @@ typedef struct TorStats {
 TOR_API int tor_context_set_stats(TorContext* ctx, int32_t enable);
 TOR_API int tor_last_stats(TorContext* ctx, TorStats* out);
 /* Debug: 8 x u64 per wave of the last launch (stats enabled): {start, end (100 MHz wall clock), bounce
- * iterations, closest-hit queries | HW_ID << 44, time when the work counter ran dry, iteration count at that
+ * iterations (low 40 bits) | stage two of the plane-screened segments << 43 (a 21-bit field like the six below, part of
+ * the object loop's), closest-hit queries | HW_ID << 44, time when the work counter ran dry, iteration count at that
  * time | trips of the resolve loop << 32, and two words of six 21-bit fields in units of 4096 shader cycles:
  * refill + camera ray, object loop, exact resolve | shade, deposit, total}.
  * Returns the number of waves copied (<= cap_waves) or < 0. */
@@ -463,7 +464,8 @@ TOR_API int tor_selftest_screen_host(int64_t n, const double* o, const double* d
                                      int32_t* keep, int32_t* need);
 /* The screen's SECOND form (expanded quadratic, direction normalised per ray: csrc/tor_screen.hpp).  variant 0: static
  * spheres through the general record, movers along y through the common-height record, other movers through the first form
- * (as the kernel routes them); variant 1: static spheres through the common-height record. */
+ * (as the kernel routes them); variant 1: static spheres through the common-height record; variant 2: static spheres and
+ * movers along y through the plane screen alone (stage one of the common-height segments). */
 TOR_API int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const double* c0,
                                       const double* dc, const int32_t* moving, const double* f, const double* r2,
                                       int32_t variant, int32_t* keep, int32_t* need);

@@ -40,6 +40,11 @@ def test_screen_never_drops_a_needed_object(tor, scale, r_lo, r_hi, origin):
     missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
     assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]], c0[missed[:1]], dcy[missed[:1]], f[missed[:1]])
     assert np.count_nonzero(need2) > n // 10
+    # stage one of the common-height segments: the plane screen alone, statics and movers along y
+    keep3, need3 = tor.selftest_screen2(o, d, c0, dcy, moving, f, r2, 2)
+    missed = np.flatnonzero((need3 != 0) & (keep3 == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]], c0[missed[:1]], dcy[missed[:1]], f[missed[:1]])
+    assert np.array_equal(need3, need2)
 
 
 def test_screen_on_the_decision_boundary(tor):
@@ -73,17 +78,18 @@ def test_screen_on_the_decision_boundary(tor):
     missed = np.flatnonzero((need != 0) & (keep == 0))
     assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
     assert 0 < np.count_nonzero(need) < n            # both sides of the boundary are present
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         keep2, need2 = tor.selftest_screen2(o, d, c0, np.zeros((n, 3)), moving, np.zeros(n), r * r, variant)
         missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
         assert missed.size == 0, (variant, missed[:5], o[missed[:1]], d[missed[:1]])
     # the same pairs as movers along y caught at a time fraction f: centre = c0 - f dc + f dc
     fm = rng.uniform(-0.5, 1.5, n)
     dcm = np.column_stack([np.zeros(n), rng.uniform(-0.5, 0.5, n), np.zeros(n)])
-    keep2, need2 = tor.selftest_screen2(o, d, c0 - dcm * fm[:, None], dcm, np.ones(n, dtype=np.int32), fm, r * r, 0)
-    missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
-    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]])
-    assert 0 < np.count_nonzero(need2) < n
+    for variant in (0, 2):
+        keep2, need2 = tor.selftest_screen2(o, d, c0 - dcm * fm[:, None], dcm, np.ones(n, dtype=np.int32), fm, r * r, variant)
+        missed = np.flatnonzero((need2 != 0) & (keep2 == 0))
+        assert missed.size == 0, (variant, missed[:5], o[missed[:1]], d[missed[:1]])
+        assert 0 < np.count_nonzero(need2) < n
 
 
 def test_screen_drops_the_obvious(tor):
@@ -125,7 +131,58 @@ def test_screen_degenerate_rays(tor):
     keep, need = tor.selftest_screen(o, d, c0, dc, moving, f, r2)
     assert np.all((need == 0) | (keep != 0)), (keep, need)
     assert keep[1] and keep[2] and need[1] and need[2]
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         keep2, need2 = tor.selftest_screen2(o, d, c0, dc, moving, f, r2, variant)
         assert np.all((need2 == 0) | (keep2 != 0)), (variant, keep2, need2)
         assert keep2[1] and keep2[2]
+
+
+
+def test_plane_screen_on_its_own_boundary(tor):
+    """Stage one of the common-height segments keeps what lies within R of the ray's GROUND TRACK.  Its own decision boundary:
+    rays whose ground track is tangent to the sphere's ground circle while the ray itself passes through the sphere's equator
+    (the 3D tangent point IS the 2D one), nudged by ulps either way; near-vertical rays (no ground track: everything is kept);
+    rays with a huge / tiny horizontal direction; and what it buys: a thin band on random_scene-like input."""
+    rng = np.random.default_rng(21)
+    n = 300_000
+    c0 = np.column_stack([rng.uniform(-11, 11, n), rng.choice([0.2, 0.7, -3.0], n), rng.uniform(-11, 11, n)])
+    r = rng.choice([0.2, 1.0, 7.5], size=n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    nrm = np.column_stack([np.cos(ang), np.zeros(n), np.sin(ang)])           # horizontal normal: a point of the equator
+    tang = np.column_stack([-np.sin(ang), np.zeros(n), np.cos(ang)])
+    up = np.array([0.0, 1.0, 0.0])
+    slope = rng.choice([0.0, 1e-3, 0.5, 3.0, 1e3, 1e8], size=(n, 1)) * rng.choice([-1.0, 1.0], size=(n, 1))
+    dirn = tang + slope * up                                                # tangent to the sphere at the equator point, any slope
+    target = c0 + nrm * r[:, None]
+    back = rng.uniform(0.5, 30.0, (n, 1))
+    o = target - dirn / np.linalg.norm(dirn, axis=1, keepdims=True) * back
+    k = rng.integers(-4, 5, size=(n, 3))
+    d = (target - o) * (1.0 + k * 2.0 ** -52) * rng.choice([1.0, 1e-6, 1e6], size=(n, 1))
+    z3 = np.zeros((n, 3)); zi = np.zeros(n, dtype=np.int32); zf = np.zeros(n)
+    keep, need = tor.selftest_screen2(o, d, c0, z3, zi, zf, r * r, 2)
+    assert np.count_nonzero((need != 0) & (keep == 0)) == 0
+    assert 0 < np.count_nonzero(need) < n
+    # the same as movers along y caught at f (centre = c0 - f dc + f dc): x and z do not move
+    fm = rng.uniform(-0.5, 1.5, n)
+    dcm = np.column_stack([np.zeros(n), rng.uniform(-0.5, 0.5, n), np.zeros(n)])
+    keep, need = tor.selftest_screen2(o, d, c0 - dcm * fm[:, None], dcm, np.ones(n, dtype=np.int32), fm, r * r, 2)
+    assert np.count_nonzero((need != 0) & (keep == 0)) == 0
+    assert 0 < np.count_nonzero(need) < n
+    # near-vertical rays through the sphere: the ground track degenerates
+    m = 50_000
+    c1 = np.column_stack([rng.uniform(-11, 11, m), np.full(m, 0.2), rng.uniform(-11, 11, m)])
+    off = _unit(rng, m) * 0.19
+    o1 = c1 + off + np.array([0.0, 5.0, 0.0])
+    tilt = rng.choice([0.0, 1e-300, 1e-120, 1e-101, 1e-99, 1e-30, 1e-9], size=(m, 2)) * rng.choice([-1.0, 1.0], size=(m, 2))
+    d1 = np.column_stack([tilt[:, 0], -np.ones(m), tilt[:, 1]])
+    keep, need = tor.selftest_screen2(o1, d1, c1, np.zeros((m, 3)), np.zeros(m, dtype=np.int32), np.zeros(m), np.full(m, 0.04), 2)
+    assert np.count_nonzero((need != 0) & (keep == 0)) == 0 and np.count_nonzero(need) > m // 2
+    # what it buys: random rays over a field of small spheres keep a thin band, a superset of the second form's candidates
+    c2 = np.column_stack([rng.uniform(-11, 11, n), np.full(n, 0.2), rng.uniform(-11, 11, n)])
+    o2 = np.column_stack([rng.uniform(-11, 11, n), rng.uniform(0.0, 2.0, n), rng.uniform(-11, 11, n)])
+    d2 = _unit(rng, n)
+    keep_p, need_p = tor.selftest_screen2(o2, d2, c2, z3, zi, zf, np.full(n, 0.04), 2)
+    keep_2, need_2 = tor.selftest_screen2(o2, d2, c2, z3, zi, zf, np.full(n, 0.04), 1)
+    assert np.count_nonzero((need_p != 0) & (keep_p == 0)) == 0
+    assert np.count_nonzero(keep_p) < 0.05 * n                      # band of width 0.4 across a field 22 wide
+    assert np.count_nonzero(keep_2) < np.count_nonzero(keep_p)      # the second form is the finer test

@@ -29,7 +29,7 @@ for waves in ("2", "3"):
         wl = raw.astype(np.float64)
         t0 = wl[:, 0].min()
         start, end = (wl[:, 0] - t0) / 100e3, (wl[:, 1] - t0) / 100e3
-        it = wl[:, 2]
+        it = wl[:, 2] & ((1 << 40) - 1)
         q = (raw[:, 3] & np.uint64((1 << 44) - 1)).astype(np.float64)
         texh = (wl[:, 4] - t0) / 100e3
         busy = (end - start).sum() / (len(wl) * end.max())

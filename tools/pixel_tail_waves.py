@@ -24,7 +24,7 @@ raw = ctx.last_wave_log()
 wl = raw.astype(np.float64)
 t0 = wl[:, 0].min()
 start, end, dry = (wl[:, 0] - t0) / 100e3, (wl[:, 1] - t0) / 100e3, (wl[:, 4] - t0) / 100e3
-it = wl[:, 2]
+it = wl[:, 2] & ((1 << 40) - 1)
 it_dry = (raw[:, 5] & np.uint64(0xffffffff)).astype(np.float64)
 hw = (raw[:, 3] >> np.uint64(44)).astype(np.int64)
 q = (raw[:, 3] & np.uint64((1 << 44) - 1)).astype(np.float64)

@@ -28,6 +28,7 @@ for seeding in (tor.SEED_SAMPLE, tor.SEED_PIXEL):
         tot = sec[:, 5].sum()
         names = ["refill+camera", "object loop", "exact resolve", "shade", "deposit"]
         share = {n: round(float(sec[:, i].sum() / tot), 3) for i, n in enumerate(names)}
-        trips = float((wl[:, 5] >> 32).sum()) / max(float(wl[:, 2].sum()), 1.0)
+        share["stage two (of the loop)"] = round(float(((wl[:, 2] >> 43) & m).sum() / tot), 3)
+        trips = float((wl[:, 5] >> 32).sum()) / max(float((wl[:, 2] & ((1 << 40) - 1)).sum()), 1.0)
         print(f"seeding {seeding} accel {accel}: trips/iter {trips:.2f}  {H * W * SPP / ms / 1e3:8.1f} Msamples/s  kernel {ms:7.2f} ms  "
               f"cand/query {st.candidates / max(st.hit_queries, 1):.2f}  {share}", flush=True)

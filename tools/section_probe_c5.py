@@ -18,5 +18,5 @@ for accel in (0, 2, 1, 3):
     sec = np.stack([wl[:, 6] & m, (wl[:, 6] >> 21) & m, (wl[:, 6] >> 42) & m, wl[:, 7] & m, (wl[:, 7] >> 21) & m, (wl[:, 7] >> 42) & m], axis=1).astype(np.float64)
     tot = sec[:, 5].sum()
     names = ["refill", "loop", "resolve", "shade", "deposit"]
-    trips = float((wl[:, 5] >> 32).sum()) / max(float(wl[:, 2].sum()), 1.0)
+    trips = float((wl[:, 5] >> 32).sum()) / max(float((wl[:, 2] & ((1 << 40) - 1)).sum()), 1.0)
     print(f"c5 accel {accel}: {H*W*SPP/ms/1e3:7.0f} Msamples/s trips/iter {trips:.1f} cand/query {st.candidates/max(st.hit_queries,1):.1f} queries/sample {st.hit_queries/max(st.samples,1):.2f}", {n: round(float(sec[:, i].sum()/tot), 3) for i, n in enumerate(names)}, flush=True)

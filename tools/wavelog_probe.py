@@ -15,7 +15,7 @@ for mode in (tor.SEED_PIXEL, tor.SEED_SAMPLE):
     start = (wl[:, 0] - t0) / 100e3; end = (wl[:, 1] - t0) / 100e3   # ms (100 MHz)
     raw = ctx.last_wave_log()
     hw = (raw[:, 3] >> np.uint64(44)).astype(np.int64); q = (raw[:, 3] & np.uint64((1 << 44) - 1)).astype(np.float64)
-    it = wl[:, 2]
+    it = wl[:, 2] & ((1 << 40) - 1)
     slot = hw & 15; simd = (hw >> 4) & 3
     rate_us = (wl[:, 1] - wl[:, 0]) / 100.0 / it
     for sl in sorted(set(slot.tolist())):

@@ -62,11 +62,12 @@ int fail_hip(hipError_t e, const char* what) {
 hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* cold_override) {
   const std::vector<double>& c = cold_override ? *cold_override : lay.cold;
   struct Part { const void* src; size_t bytes; size_t off; };
-  Part parts[9] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
+  Part parts[10] = {{lay.stat.data(), lay.stat.size() * 8, 0}, {lay.mov.data(), lay.mov.size() * 8, 0},
                    {lay.movy.data(), lay.movy.size() * 8, 0}, {lay.segs.data(), lay.segs.size() * 8, 0},
                    {c.data(), c.size() * 8, 0},               {lay.hot32.data(), lay.hot32.size() * 4, 0},
                    {lay.coop_trips.data(), lay.coop_trips.size() * 8, 0},
-                   {lay.xsegs.data(), lay.xsegs.size() * 8, 0}, {lay.xrec.data(), lay.xrec.size() * 8, 0}};
+                   {lay.xsegs.data(), lay.xsegs.size() * 8, 0}, {lay.xrec.data(), lay.xrec.size() * 8, 0},
+                    {lay.xpl.data(), lay.xpl.size() * 8, 0}};
   size_t total = 0;
   for (Part& p : parts) {
     p.off = total;
@@ -87,8 +88,10 @@ hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* c
   coop_trips = (const double*)(b + parts[6].off);
   xsegs = (const double*)(b + parts[7].off);
   xrec = (const double*)(b + parts[8].off);
+  xpl = (const double*)(b + parts[9].off);
   n_segs = lay.n_segs;
   n_sorted = (int)lay.n_sorted;
+  n_xrec = (int)lay.xrec.size();
   has_f32 = false;
   for (int s = 0; s < lay.n_segs; ++s) has_f32 = has_f32 || lay.segs[8 * (size_t)s] >= 5.0;
   return e;
@@ -352,6 +355,8 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = tor::knob("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
   if (const char* c = tor::knob("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
   if (const char* c = tor::knob("TOR_SCREEN")) ctx->screen = std::atoi(c) != 0;
+  if (const char* c = tor::knob("TOR_PLANE")) ctx->plane_screen = std::atoi(c) != 0;
+  if (const char* c = tor::knob("TOR_PLANE_LDS")) ctx->plane_lds = std::atoi(c) != 0;
   if (const char* c = tor::knob("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
   if (const char* c = tor::knob("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
   if (const char* c = tor::knob("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
@@ -564,6 +569,14 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       q.hot32 = L.has_f32 ? L.hot32 : nullptr;
       q.xsegs = L.xsegs;
       q.xrec = L.xrec;
+      q.xpl = ctx->plane_screen ? L.xpl : nullptr;
+      // stage two of the plane-screened segments reads 32-byte records per lane: from LDS when the table fits beside the
+      // per-wave queues at this launch's workgroups per CU (random_scene: 15.9 KB + 18.7 KB of 53 KB), else through the vector cache
+      q.xrec_lds_doubles = 0;
+      if (q.xpl != nullptr && ctx->plane_lds) {
+        const size_t wgs = (size_t)std::max(1, ctx->max_blocks_per_cu[o.seeding][0]);
+        if ((size_t)L.n_xrec * 8 + (size_t)tor::integrate_fixed_lds_bytes(0, 0) <= (size_t)(160 * 1024) / wgs - 1024) q.xrec_lds_doubles = L.n_xrec;
+      }
       q.n_segs = L.n_segs;
     };
     const bool blocks_avail = (accel & TOR_ACCEL_BLOCKS) && ctx->accel_built[v32] && ctx->accel[v32].available;
@@ -1396,7 +1409,8 @@ int tor_selftest_screen_host(int64_t n, const double* o, const double* d, const 
 
 // The SECOND form of the screen (tor_screen.hpp: expanded quadratic, normalised direction) on the host, same conventions as
 // tor_selftest_screen_host.  variant 0: a static sphere through the general record (kind 10), a mover along y through kind 12,
-// any other mover through the first form (as the kernel does); variant 1: static spheres through the common-height record (kind 11).
+// any other mover through the first form (as the kernel does); variant 1: static spheres through the common-height record (kind 11);
+// variant 2: statics and movers along y through the PLANE screen (stage one of kinds 11 / 12) alone.
 int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const double* c0, const double* dc,
                               const int32_t* moving, const double* f, const double* r2, int32_t variant, int32_t* keep, int32_t* need) {
   if (n < 0 || !o || !d || !c0 || !dc || !moving || !f || !r2 || !keep || !need)
@@ -1413,7 +1427,10 @@ int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const
     const double travel = mv ? up(std::sqrt(dcc[0] * dcc[0] + dcc[1] * dcc[1] + dcc[2] * dcc[2])) : 0.0;
     const tor::ScreenRay ray = tor::screen2_ray(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a);
     int word;
-    if (mv) {
+    if (variant == 2) {  // stage one of kinds 11 / 12: the plane screen alone (R = this object's radius)
+      const tor::PlaneSeg ps = tor::plane_seg(ray, tor::plane_ray(ray), reach, travel, mv ? f[i] : 0.0, r2[i]);
+      word = tor::plane_word(ps, cc0[0], cc0[2]);
+    } else if (mv) {
       const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, travel, cc0[1], f[i]);
       word = tor::screen2_movy_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]), dcc[1]);
     } else if (variant == 1) {

@@ -270,6 +270,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     __syncthreads();
   }
 
+  // ARITH 2: the second-form records of the screen for stage two of the plane-screened segments (kernel/integrate_loop_plane.inc)
+  const bool xstaged = ARITH == 2 && p.xrec_lds_doubles > 0;
+  if (ARITH == 2 && xstaged) {
+    for (int k = threadIdx.x; k < p.xrec_lds_doubles; k += kThreads) stage[k] = p.xrec[k];
+    __syncthreads();
+  }
+
   if (SEEDING == 1) {
     if (lane < kAccSlots) {
       tag_lds[lane] = -1;
@@ -335,7 +342,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   // loop, kept in LDS (lane 0) so that the counters cost no registers when they are off
   const bool prof = p.wave_log != nullptr;
   enum { kSecRefill = 0, kSecLoop, kSecResolve, kSecShade, kSecDeposit, kSecTrips, kSecBegin, kSecMark,
-         kStQueries, kStCand, kStIters, kStSamples, kLogStart, kLogExhausted, kLogItersAtExhaustion };
+         kStQueries, kStCand, kStIters, kStSamples, kLogStart, kLogExhausted, kLogItersAtExhaustion, kSecStage2 };
+  static_assert(kSecStage2 < kProfSlots, "debug counters");
   if ((stats_on || prof) && lane == 0) {
     for (int k = 0; k < kProfSlots; ++k) prof_lds[k] = 0;
     prof_lds[kSecBegin] = prof_lds[kSecMark] = __builtin_readcyclecounter();
@@ -432,10 +440,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       // ARITH 2 (conservative FMA screen, screen_filter above): the ray's share of the margins
       double scr_s1 = 0.0, scr_d1 = 0.0, scr_negmu = 0.0, scr_am = 0.0;
       ScreenRay sray{};  // second form of the screen (tor_screen.hpp): the normalised direction, once per query
+      PlaneRay pray{0.0, 0.0, 0.0, true};  // ... and the ground track's normal for the plane screen in front of it (launches with KParams.xpl)
       if (kScreen) {
         scr_s1 = __builtin_fabs(ox) + __builtin_fabs(oy) + __builtin_fabs(oz);
         scr_d1 = __builtin_fabs(dx) + __builtin_fabs(dy) + __builtin_fabs(dz);
         sray = screen2_ray(ox, oy, oz, dx, dy, dz, a_strict);
+        if (p.xpl != nullptr) pray = plane_ray(sray);
       }
 
       // TOR_ACCEL_F32: the ray in float32, relative to the scene origin (used by segment kinds 5-7 only)
@@ -483,6 +493,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         unsigned nz = 0;    // kWords: bit (w_count - 1 - k) <-> word k of this pass is not empty
         int w_count = 0;    // kWords: words stored in this pass (wave-uniform)
         int gb_next = 0;    // kWords: the block index behind the last block tested (wave-uniform)
+        bool plane_ran = false;  // kWords: stage two of a plane-screened segment cleared bits of this pass's words (wave-uniform)
         // (seg, i) are the same in every lane that has a live path, but they are updated under `if (active)` inside
         // this loop, which makes them divergent in the compiler's eyes -- and the object records would then come
         // through vector loads instead of the scalar data path (measured: half the speed).  readfirstlane inside
@@ -515,7 +526,9 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           // normalised per ray -- 8 / 6 / 9 float64 instructions per object, all but one fused multiply-adds against scalar
           // operands); the others keep the first form below
           const int xkind = kScreen ? (int)as_const(p.xsegs)[seg * 8 + 0] : 0;
-          if (kScreen && xkind >= 10) {
+          if (kScreen && xkind >= 11 && p.xpl != nullptr) {
+#include "kernel/integrate_loop_plane.inc"
+          } else if (kScreen && xkind >= 10) {
 #include "kernel/integrate_loop_screen2.inc"
           } else if (seg_kind == 0) {
 #include "kernel/integrate_loop_f64_static.inc"
@@ -539,6 +552,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             q[(unsigned)w_count * 64] = mw;
             nz = push_cond(nz, mw != 0u);
             w_count += 1;
+          }
+          if (plane_ran) {  // stage two emptied words: the summary again, from the words as they are now
+            nz = 0;
+            for (int k2 = 0; k2 < w_count; ++k2) nz = push_cond(nz, q[(unsigned)k2 * 64] != 0u);
           }
         }
         }  // if (active)
@@ -604,12 +621,13 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0 && p.wave_log != nullptr) {
       unsigned long long* w = p.wave_log + (size_t)(blockIdx.x * (kThreads / 64) + wave) * 8;
-      w[0] = prof_lds[kLogStart]; w[1] = wall_clock64(); w[2] = prof_lds[kStIters];
+      w[0] = prof_lds[kLogStart]; w[1] = wall_clock64();
       w[3] = prof_lds[kStQueries] | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) << 44);  // HW_ID[15:0]
       w[4] = prof_lds[kLogExhausted]; w[5] = (prof_lds[kLogItersAtExhaustion] & 0xffffffffull) | (prof_lds[kSecTrips] << 32);
       // six 21-bit fields in units of 4096 shader cycles: refill+camera, object loop, exact resolve | shade, deposit, total
       const unsigned long long total = __builtin_readcyclecounter() - prof_lds[kSecBegin];
       auto f21 = [](unsigned long long c) { c >>= 12; return c > 0x1fffffull ? 0x1fffffull : c; };
+      w[2] = (prof_lds[kStIters] & 0xffffffffffull) | (f21(prof_lds[kSecStage2]) << 43);  // bounce iterations | stage two of the plane-screened segments (part of the object loop's field)
       w[6] = f21(prof_lds[kSecRefill]) | (f21(prof_lds[kSecLoop]) << 21) | (f21(prof_lds[kSecResolve]) << 42);
       w[7] = f21(prof_lds[kSecShade]) | (f21(prof_lds[kSecDeposit]) << 21) | (f21(total) << 42);
     }
@@ -657,7 +675,7 @@ static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? ((p.two_level != 0 && wants_f32(p) != 0) ? 2 : 1) : 0; }
 static size_t dynamic_lds(const KParams& p) {
   return (size_t)wave_lds_bytes(wants_blocks(p), coop_variant(wants_f32(p), wants_blocks(p))) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
-         (size_t)p.bnd32_lds_floats * 4;
+         (size_t)p.bnd32_lds_floats * 4 + (size_t)p.xrec_lds_doubles * 8;
 }
 
 // arith as the caller asked (0 strict, 1 fused) -> the kernel variant: strict launches of the brute-force layouts run behind

@@ -211,11 +211,12 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     // (kinds 1 / 2 without a second-form record keep the first form of the screen: xkind 0)
     cut_by_y(groups[gi].ids, y ? 1 : 2, t0, dt, 0, (y && std::isfinite(t0) && std::isfinite(dt) && dt != 0.0) ? 12 : 0);
   }
-  size_t n_stat_p = 0, n_mov_p = 0, n_movy_p = 0, n_xrec = 0;
+  size_t n_stat_p = 0, n_mov_p = 0, n_movy_p = 0, n_xrec = 0, n_xpl = 0;
   for (const Seg64& sg : segs64) {
     const size_t cp = padded(sg.ids.size());
     (sg.kind == 0 ? n_stat_p : (sg.kind == 1 ? n_movy_p : n_mov_p)) += cp;
     n_xrec += cp * (sg.xkind != 0 ? 4 : 0);
+    n_xpl += cp * (sg.xkind >= 11 ? 2 : 0);
   }
   std::vector<char> yonly32(groups32.size(), 0);
   size_t n32_slots = padded(statics32.size()), n32_floats = padded(statics32.size()) / 2 * 10;
@@ -232,6 +233,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   out.mov.assign(8 * n_mov_p + 8, 0.0);
   out.movy.assign(6 * n_movy_p + 8, 0.0);
   out.xrec.assign(n_xrec + 8, 0.0);
+  out.xpl.assign(n_xpl + 8, 1e300);  // padding: far from every ground track (a ray that keeps everything keeps it too: the second form drops it)
   out.hot32.assign(n32_floats + 32, 0.0f);
   out.cold.assign(16 * out.n_sorted + 16, 0.0);
   out.segs.clear();
@@ -246,17 +248,19 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   // know about the segment's members (tor_kernels.hip: screen_filter) -- an upper bound of |c0| + |r| and of |c1 - c0|.  A
   // non-finite bound turns into infinite margins there: everything is kept and the exact test decides.
   auto up = [](double x) { return x * (1.0 + 0x1p-40); };
-  size_t sorted = 0, stat_rec = 0, mov_rec = 0, movy_rec = 0, x_off = 0;
+  size_t sorted = 0, stat_rec = 0, mov_rec = 0, movy_rec = 0, x_off = 0, pl_off = 0;
   for (const Seg64& sg : segs64) {
     const size_t cnt_p = padded(sg.ids.size());
-    double reach = 0.0, travel = 0.0;
+    double reach = 0.0, travel = 0.0, rmax2 = 0.0;
     for (int64_t idx : sg.ids) {
       if (sg.kind == 0) {
         const TorSphere& s = objs[idx].u.sphere;
         reach = std::fmax(reach, norm3(s.center.x, s.center.y, s.center.z) + std::fabs(s.radius));
+        rmax2 = std::fmax(rmax2, s.radius * s.radius);
       } else {
         const TorMovingSphere& s = objs[idx].u.moving_sphere;
         reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
+        rmax2 = std::fmax(rmax2, s.radius * s.radius);
         travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
       }
     }
@@ -265,7 +269,9 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     out.segs.insert(out.segs.end(), {(double)sg.kind, (double)first_rec, (double)(cnt_p | ((cnt_p - sg.ids.size()) << 24)), (double)(sorted / kPad),
                                      sg.kind == 0 ? 0.0 : sg.t0, sg.kind == 0 ? 0.0 : sg.dt, up(reach), up(travel)});
     // second-form records of the screen (tor_screen.hpp): {xkind, first float64 of the records, common c0.y}
-    out.xsegs.insert(out.xsegs.end(), {(double)sg.xkind, (double)x_off, sg.y, 0.0, 0.0, 0.0, 0.0, 0.0});
+    // ... and of its stage one (kinds 11 / 12): first float64 of the segment's {cx, cz} pairs in xpl, largest radius^2 (a NaN
+    // radius: fmax skipped it -- and the reference can never hit that sphere)
+    out.xsegs.insert(out.xsegs.end(), {(double)sg.xkind, (double)x_off, sg.y, (double)pl_off, rmax2, 0.0, 0.0, 0.0});
     const size_t xs = sg.xkind != 0 ? 4 : 0;
     for (size_t k = 0; k < cnt_p && xs != 0; ++k) {  // padding: never a candidate (t'' = T - 1e300 < 0, disc'' < 0), except for a wild ray, which the exact test rejects
       double* x = &out.xrec[x_off + xs * k];
@@ -280,7 +286,10 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
         m[3] = s.radius * s.radius;
         double* x = &out.xrec[x_off + 4 * k];
         if (sg.xkind == 10) { x[0] = s.center.x; x[1] = s.center.y; x[2] = s.center.z; x[3] = screen2_K(s.center.x, s.center.y, s.center.z, s.radius * s.radius); }
-        else { x[0] = s.center.x; x[1] = s.center.z; x[2] = screen2_Ky(s.center.x, s.center.z, s.radius * s.radius); x[3] = 0.0; }
+        else {
+          x[0] = s.center.x; x[1] = s.center.z; x[2] = screen2_Ky(s.center.x, s.center.z, s.radius * s.radius); x[3] = 0.0;
+          out.xpl[pl_off + 2 * k] = s.center.x; out.xpl[pl_off + 2 * k + 1] = s.center.z;
+        }
       } else {
         const TorMovingSphere& s = hv.u.moving_sphere;
         const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
@@ -293,6 +302,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
             double* x = &out.xrec[x_off + 4 * k];
             x[0] = s.center0.x; x[1] = s.center0.z; x[2] = screen2_Ky(s.center0.x, s.center0.z, s.radius * s.radius);
             x[3] = dcy;
+            out.xpl[pl_off + 2 * k] = s.center0.x; out.xpl[pl_off + 2 * k + 1] = s.center0.z;
           }
         } else {
           double* m = &out.mov[8 * (mov_rec + k)];
@@ -305,6 +315,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     }
     (sg.kind == 0 ? stat_rec : (sg.kind == 1 ? movy_rec : mov_rec)) += cnt_p;
     x_off += cnt_p * xs;
+    pl_off += cnt_p * (sg.xkind >= 11 ? 2 : 0);
     sorted += cnt_p;
   }
 

@@ -18,6 +18,9 @@ struct HostLayout {
   // common c0.y, 12 mover along y with a common c0.y), first float64 of its records in xrec, the common c0.y, 0...}; records
   // {cx, cy, cz, K} | {cx, cz, K', 0} | {cx, cz, K', dcy}: 4 float64 each, padded like the first form's
   std::vector<double> xsegs, xrec;
+  // stage one in front of it (tor_screen.hpp: the plane screen, kinds 11 / 12 only): {cx, cz} per slot -- 16 bytes, the wave-uniform
+  // loop reads nothing else -- at xpl[xsegs[3] + 2 * slot of the segment]; xsegs[4] = the largest radius^2 of the segment
+  std::vector<double> xpl;
   std::vector<float> hot32;  // TOR_ACCEL_F32 segments (kinds 5/6/7): packed pair records, see tor_kernels.hpp
   int n_segs = 0;
   size_t n_sorted = 0;  // cold slots (padded)
