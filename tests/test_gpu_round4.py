@@ -4,7 +4,8 @@
  * two chain hand-off launches on one GPU (a device list that repeats an ordinal, SEED_PIXEL, >= 32 spp) are chained, not interleaved;
  * the hand-off's stall escape: waiting servers that see no progress flag the frame, the blocking entry points render it again;
  * canvas gamma other than 2.2 (canvas.nim:47-54) in both stream modes, pow_pos device == oracle on those exponents;
- * per-sample streams of configs[2] rows against the pinned LIBM oracle."""
+ * per-sample streams of configs[2] rows against the pinned LIBM oracle;
+ * the plane screen in front of the FMA screen's second form: same canvas, same candidates (TOR_PLANE, TOR_PLANE_LDS)."""
 import os
 import shutil
 import subprocess
@@ -230,3 +231,73 @@ def test_configs2_sample_stream_rows_against_the_pinned_libm_oracle(tor, oracle,
         libm = oracle.render(h, w, spp, ref_camera, objs, seeding=1, math=0, accum=0, rows=(row, row + 1)).pixels[row]
         err = float(np.max(np.abs(got[row] - libm)))
         assert err < 1e-8 <= TOL, err
+
+
+def _many_heights_scene(tor, rng):
+    """~700 objects (two passes of the 512-slot candidate words): statics at three heights in groups that are no multiple of 8
+    or 32, movers along y at two heights in two (time0, time1) groups, a few general movers, big spheres and the ground."""
+    recs = [[0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0]]
+    def add(n, y, mover, t0=0.0, t1=1.0, r=0.2, spread=13.0):
+        for i in range(n):
+            x, z = rng.uniform(-spread, spread, 2)
+            mat = [0, 0, 0, 1, 2][i % 5]
+            if mover == 0:
+                recs.append([0, x, y, z, x, y, z, 0, 1, r, mat, .6, .5, .4, 0.2, 1.5])
+            elif mover == 1:
+                recs.append([1, x, y, z, x, y + rng.uniform(0, .5), z, t0, t1, r, mat, .3, .7, .4, 0.1, 1.5])
+            else:
+                recs.append([1, x, y, z, x + rng.uniform(-.4, .4), y + .1, z + rng.uniform(-.4, .4), t0, t1, r, mat, .3, .3, .8, 0.0, 1.4])
+    add(150, 0.2, 0); add(37, 0.35, 0, r=0.35); add(9, 0.5, 0, r=0.5); add(5, 0.77, 0, r=0.1)
+    add(211, 0.2, 1); add(75, 0.3, 1, t0=0.25, t1=0.75, r=0.3); add(44, 0.2, 1, t0=0.25, t1=0.75); add(13, 0.2, 1, r=0.05)
+    add(21, 0.25, 2); add(11, 0.25, 2, t0=-1.0, t1=2.0)
+    for c in ((0, 1, 0), (-4, 1, 0), (4, 1, 0)):
+        recs.append([0, *c, *c, 0, 1, 1.0, 2 if c[0] == 0 else 1, .7, .6, .5, 0.0, 1.5])
+    order = rng.permutation(len(recs))
+    return tor.Scene.from_records(np.asarray(recs, dtype=np.float64)[order])
+
+
+def test_plane_screen_never_changes_a_pixel_nor_a_candidate(tor, oracle, ref_scene, ref_camera):
+    """Stage one of the common-height segments (csrc/tor_screen.hpp: the plane screen, 4 instructions per object) keeps a band
+    along the ray's ground track; stage two runs the screen's second form per lane on what it keeps.  Claim: what is left is
+    EXACTLY what the second form alone leaves.  TOR_PLANE=0 is that second form on every object: same canvas bit for bit and
+    the same number of candidates in the resolve pass -- on the screen test's four scenes, on a 700-object scene with segments of
+    awkward sizes at several heights (two passes of the candidate words, words shared by two segments), on a frame of the
+    1601-object animation, both stream layouts, records from LDS and through the vector cache; == the oracle."""
+    import torch
+    from test_gpu_round3 import _render_with_env, _screen_scenes
+    rng = np.random.default_rng(77)
+    scenes = _screen_scenes(tor) + [("many heights", _many_heights_scene(tor, rng), tor.camera(look_from=(11, 2.2, 5), aperture=0.05))]
+    anim = tor.Animation(108, 192)
+    a_cam, a_scene, _ = next(iter(anim.scenes(skip=40)))
+    scenes.append(("animation frame", a_scene, a_cam))
+    for name, scene, cam in scenes:
+        for seeding in (tor.SEED_SAMPLE, tor.SEED_PIXEL):
+            off, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {"TOR_PLANE": "0"}, seeding=seeding, accel=0)
+            on, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {}, seeding=seeding, accel=0)
+            assert torch.equal(on, off), (name, seeding, int((on != off).sum()))
+            vec, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {"TOR_PLANE_LDS": "0"}, seeding=seeding, accel=0)
+            assert torch.equal(vec, off), (name, seeding, "records through the vector cache")
+            assert float(on.abs().sum()) > 0.0
+    objs, _ = ref_scene
+    h, w, spp = 90, 160, 32
+    for seeding in (0, 1):
+        want = oracle.render(h, w, spp, ref_camera, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels
+        got, _ = _render_with_env(tor, tor.random_scene(0xFACADE), tor.camera(), h, w, spp, {}, seeding=seeding, accel=0)
+        _exact(got.cpu().numpy(), want)
+    # candidates of the resolve pass: identical with and without stage one
+    for name, scene, cam in (scenes[0], scenes[4]):
+        stats = {}
+        for key, env in (("second form", {"TOR_PLANE": "0"}), ("plane + second form", {}), ("records not in LDS", {"TOR_PLANE_LDS": "0"})):
+            with _env(**env):
+                ctx = tor.Context(0)
+            ctx.upload(scene.list())
+            ctx.set_stats(True)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+            ctx.render_device(cam, h, w, 8, 2.2, 50, tor.make_options(seeding=tor.SEED_SAMPLE, accel=0), buf.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            stats[key] = ctx.last_stats()
+            ctx.close()
+        a, b, c = stats["second form"], stats["plane + second form"], stats["records not in LDS"]
+        assert a.hit_queries == b.hit_queries == c.hit_queries and a.samples == b.samples
+        assert a.candidates == b.candidates == c.candidates, (name, a.candidates, b.candidates, c.candidates)

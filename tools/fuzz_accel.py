@@ -1,5 +1,6 @@
 """Differential fuzz of the exact accelerations on the GPU: random scenes and cameras, every accel mode -- and the brute force
-WITHOUT its conservative FMA screen (TOR_SCREEN=0) -- against the float64 brute-force canvas, bit for bit.
+WITHOUT its conservative FMA screen (TOR_SCREEN=0, DESIGN 4.11: no plane screen, no second form, the reference's unfused
+discriminant for every object) -- against the float64 brute-force canvas, bit for bit.
 Usage: python tools/fuzz_accel.py [seconds] [seed]"""
 import importlib
 import os
@@ -25,8 +26,13 @@ def random_scene(rng):
         recs.append([0, shift[0], shift[1] - R, shift[2], shift[0], shift[1] - R, shift[2], 0, 1, R, 0, .5, .5, .5, 0, 0])
     mover_frac = float(rng.choice([0.0, 0.5, 0.9]))
     general = rng.random() < 0.4
+    # spheres resting at a few common heights (bit-identical c0.y: the strict loop's common-height segments and the plane screen in
+    # front of them) in half of the scenes; any height in the others
+    levels = shift[1] + rng.uniform(0, 0.3 * spread, int(rng.integers(1, 5))) if rng.random() < 0.5 else None
     while len(recs) < n:
         c = shift + np.array([rng.uniform(-spread, spread), rng.uniform(0, 0.3 * spread), rng.uniform(-spread, spread)])
+        if levels is not None and rng.random() < 0.9:
+            c[1] = levels[int(rng.integers(0, len(levels)))]
         r = float(rng.choice([0.15, 0.2, 0.3, 0.45, 1.0])) * rscale * (1 if rng.random() > 0.03 else -1)
         mat = int(rng.integers(0, 3))
         alb = rng.uniform(0.1, 0.95, 3)
