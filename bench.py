@@ -689,8 +689,10 @@ def main():
             "note": "the path is float64-VALU bound by design (scene in SGPRs via the scalar cache, 24 B of HBM per pixel).  achieved = "
                     "samples/s x the reference formulation's float64 operation count (SURVEY 8d).  The reference's arithmetic has no FMA "
                     "(0.5 of the FMA peak would be its ceiling); the object loop therefore SCREENS every ray x object pair with a "
-                    "conservative FMA form of the same quadratic (11-14 instructions, csrc/tor_screen.hpp) and runs the reference's unfused "
-                    "operations only on the candidates -- same canvas bit for bit (`unscreened` = without it)",
+                    "conservative float64 FMA form of the same geometry (csrc/tor_screen.hpp: 4 instructions per object for the distance to the "
+                    "vertical plane through the ray, then the expanded quadratic -- 7 to 10 -- on the ~9 objects per query that keeps) and runs "
+                    "the reference's unfused operations only on the candidates -- same canvas bit for bit (`unscreened` = without any of "
+                    "it, `second_form_only` = without the plane stage)",
         }
         if args.accel != "none":
             # with an exact acceleration the rate is still quoted against the reference's brute-force
@@ -709,8 +711,9 @@ def main():
             "config": {"workload": f"{config_name(W, H, spp, max(world, 1), args.scaling)}: random_scene seed 0xFACADE (485 objects), {W}x{H}, "
                                    f"{spp} spp, depth {args.depth}",
                        "seeding": args.seeding, "arith": args.arith, "accel": args.accel,
-                       "object_loop": ("every ray x every object in float64; conservative FMA screen, candidates re-tested with the reference's "
-                                       "unfused operations (TOR_SCREEN=0 turns the screen off)") if (args.accel == "none" and args.arith == "strict"
+                       "object_loop": ("every ray x every object in float64; conservative FMA screen in two stages (plane through the ray, then the "
+                                       "expanded quadratic), candidates re-tested with the reference's unfused operations (TOR_SCREEN=0 turns "
+                                       "the screen off, TOR_PLANE=0 its first stage)") if (args.accel == "none" and args.arith == "strict"
                                                                                                      and os.environ.get("TOR_SCREEN", "1") != "0") else "see accel / arith",
                        "timed_region": "scene + camera resident in HBM, frame stays on the device (harness contract); "
                                        "SURVEY 8(d)'s host-canvas region is reported beside it as `host_canvas`",
@@ -772,9 +775,27 @@ def main():
                 "value": round(total_samples * aux / dt2 / 1e6, 2), "unit": "Msamples/s", "steps": aux, "ms_per_step": round(dt2 / aux * 1e3, 3),
                 "canvas_identical_to_value_frame": same,
                 "note": "TOR_SCREEN=0: 17 / 19 / 23 unfused float64 operations per ray x object in the wave-uniform loop (the reference's "
-                        "discriminant as written) instead of the 11 / 12 / 14-instruction conservative FMA screen; candidates get the "
-                        "reference's exact test either way"}
+                        "discriminant as written) instead of the conservative FMA screen; candidates get the reference's exact test either way"}
             ctx0.close()
+            # ... and with the screen's second form on EVERY object (round 4 before the plane stage)
+            os.environ["TOR_PLANE"] = "0"
+            ctx1 = tor.Context(dev_index)
+            os.environ.pop("TOR_PLANE", None)
+            ctx1.upload(scene.list())
+            ctx1.render_device(cam, H, W, spp, 2.2, args.depth, opt, frame.data_ptr(), stream)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref_frame, frame))
+            t1 = time.perf_counter()
+            for _ in range(aux):
+                ctx1.render_device(cam, H, W, spp, 2.2, args.depth, opt, frame.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            result["second_form_only"] = {
+                "value": round(total_samples * aux / dt3 / 1e6, 2), "unit": "Msamples/s", "steps": aux, "ms_per_step": round(dt3 / aux * 1e3, 3),
+                "canvas_identical_to_value_frame": same,
+                "note": "TOR_PLANE=0: the screen's second form (7 / 9 / 10 instructions per common-height static / static / mover along y) on "
+                        "every ray x object, without the 4-instruction plane screen in front of it"}
+            ctx1.close()
         notes = {"f32": "every ray x every object, through the conservative packed-float32 pre-filter first "
                         "(tor_filter32.hpp); kept objects get the reference's float64 test",
                  "blocks": "SURVEY 8 f4: spatial blocks of 8 objects behind conservative boxes",

@@ -186,3 +186,63 @@ def test_plane_screen_on_its_own_boundary(tor):
     assert np.count_nonzero((need_p != 0) & (keep_p == 0)) == 0
     assert np.count_nonzero(keep_p) < 0.05 * n                      # band of width 0.4 across a field 22 wide
     assert np.count_nonzero(keep_2) < np.count_nonzero(keep_p)      # the second form is the finer test
+
+
+def test_strict_layout_walk_on_the_host(tor):
+    """The strict brute-force layout as tor_scene_upload builds it (common-height segments, their {cx, cz} plane table, the
+    segment's largest radius, padding) walked on the host the way the ARITH 2 object loop walks it: plane screen first, second
+    form on what it keeps.  For every ray x object: what the reference's test needs (tor_selftest_screen_host's `need`) is a
+    candidate; objects end up on the segments they belong to; the plane screen is the coarser test."""
+    import importlib
+    rng = np.random.default_rng(31)
+    base = tor.random_scene(0xFACADE)
+    recs = base.to_records()
+    # second scene: three heights, two time groups, general movers, radii mixed inside a height, group sizes below / above 8
+    extra = []
+    def add(n, y, mover, t0=0.0, t1=1.0):
+        for i in range(n):
+            x, z = rng.uniform(-9, 9, 2)
+            r = float(rng.choice([0.1, 0.2, 0.4]))
+            if mover == 0:
+                extra.append([0, x, y, z, x, y, z, 0, 1, r, 0, .5, .5, .5, 0, 0])
+            elif mover == 1:
+                extra.append([1, x, y, z, x, y + rng.uniform(0, .5), z, t0, t1, r, 0, .5, .5, .5, 0, 0])
+            else:
+                extra.append([1, x, y, z, x + .3, y, z - .2, t0, t1, r, 0, .5, .5, .5, 0, 0])
+    add(41, 0.2, 0); add(7, 0.9, 0); add(19, 0.4, 0); add(53, 0.2, 1); add(12, 0.4, 1, 0.25, 0.75); add(5, 0.3, 1); add(9, 0.2, 2)
+    extra.append([0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0])
+    mixed = np.asarray(extra, dtype=np.float64)[rng.permutation(len(extra))]
+    for recs_k, want_kinds in ((recs, {10, 11, 12}), (mixed, {0, 10, 11, 12})):
+        scene = tor.Scene.from_records(recs_k)
+        n_obj = len(recs_k)
+        n_rays = 400
+        # rays that start on or near objects (scattered rays) and camera-like rays
+        pick = rng.integers(0, n_obj, n_rays)
+        c = recs_k[pick, 1:4]
+        o = c + _unit(rng, n_rays) * (np.abs(recs_k[pick, 9])[:, None] * rng.choice([1.0, 1.0, 3.0, 40.0], size=(n_rays, 1)))
+        d = _unit(rng, n_rays) * rng.choice([1.0, 1e-3, 1e3], size=(n_rays, 1))
+        aim = rng.random(n_rays) < 0.5                      # half of them aimed at some other object
+        tgt = recs_k[rng.integers(0, n_obj, n_rays), 1:4] + rng.normal(0, 0.1, (n_rays, 3))
+        d[aim] = (tgt - o)[aim]
+        d[:4] = [[0, -1, 0], [0, 1, 0], [1e-200, -1, 0], [0, -1, 1e-40]]   # vertical: no ground track
+        t = rng.uniform(-0.2, 1.2, n_rays)
+        keep, kind = tor.debug_screen2_scene(scene.list(), o, d, t)
+        assert set(np.unique(kind)) == want_kinds, np.unique(kind)
+        is_static = recs_k[:, 0] == 0
+        y_mover = (~is_static) & (recs_k[:, 4] == recs_k[:, 1]) & (recs_k[:, 6] == recs_k[:, 3])
+        assert np.all(kind[~is_static & ~y_mover] == 0) and np.all(np.isin(kind[is_static], (10, 11))) and np.all(np.isin(kind[y_mover], (0, 12)))
+        assert np.all((keep == 3) == (kind == 0)[None, :])
+        # need: the reference's own test per pair
+        R, O = np.meshgrid(np.arange(n_rays), np.arange(n_obj), indexing="ij")
+        R, O = R.ravel(), O.ravel()
+        c0 = recs_k[O, 1:4]; dc = recs_k[O, 4:7] - c0
+        mv = (recs_k[O, 0] != 0).astype(np.int32)
+        f = np.where(mv != 0, (t[R] - recs_k[O, 7]) / (recs_k[O, 8] - recs_k[O, 7]), 0.0)
+        _, need = tor.selftest_screen(o[R], d[R], c0, dc, mv, f, recs_k[O, 9] ** 2)
+        need = need.reshape(n_rays, n_obj) != 0
+        on_second_form = keep != 3
+        assert np.count_nonzero(need & on_second_form) > 100
+        assert np.all(keep[need & on_second_form] == 2), np.argwhere(need & on_second_form & (keep != 2))[:5]
+        plane_segments = np.isin(kind, (11, 12))[None, :] & on_second_form
+        assert np.count_nonzero(keep[plane_segments] == 0) > 0.8 * np.count_nonzero(plane_segments)   # most pairs end at stage one
+        assert np.all(keep[:4][plane_segments[:4]] >= 1)            # vertical rays: the plane screen keeps everything

@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
     "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
-    "tor_selftest_screen2_host", "tor_knob_count", "tor_knob_info", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
+    "tor_selftest_screen2_host", "tor_debug_screen2_scene", "tor_knob_count", "tor_knob_info", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
 ]
 
 _lib = None
@@ -241,6 +241,7 @@ def lib():
         [C.POINTER(C.c_double)] * 2 + [C.c_int32] + [C.POINTER(C.c_int32)] * 2
     L.tor_selftest_slab32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int32)] * 2
     L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
+    L.tor_debug_screen2_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -765,6 +766,19 @@ def debug_filter32_scene(world: HittableList, o, d, time):
     _check(lib().tor_debug_filter32_scene(world, len(time), o.ctypes.data_as(P), d.ctypes.data_as(P), time.ctypes.data_as(P),
                                           keep.ctypes.data_as(C.POINTER(C.c_int8))))
     return keep
+
+
+def debug_screen2_scene(world: HittableList, o, d, time):
+    """(keep[n_rays, n_objects] int8, kind[n_objects] int32): the strict layout's second-form segments walked on the host --
+    0 dropped by the plane screen, 1 dropped by the second form, 2 candidate, 3 first-form segment; kind 0 | 10 | 11 | 12."""
+    dp = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    o, d, time = dp(o), dp(d), dp(time)
+    keep = np.zeros((len(time), int(world.len)), dtype=np.int8)
+    kind = np.zeros(int(world.len), dtype=np.int32)
+    P = C.POINTER(C.c_double)
+    _check(lib().tor_debug_screen2_scene(world, len(time), o.ctypes.data_as(P), d.ctypes.data_as(P), time.ctypes.data_as(P),
+                                         keep.ctypes.data_as(C.POINTER(C.c_int8)), kind.ctypes.data_as(C.POINTER(C.c_int32))))
+    return keep, kind
 
 
 def selftest_math(op: int, x: np.ndarray, y: np.ndarray | None = None, where: str = "device", device: int = -1):

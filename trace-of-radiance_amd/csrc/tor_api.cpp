@@ -1503,6 +1503,62 @@ int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double
   return TOR_OK;
 }
 
+// The strict brute-force layout's SECOND-FORM segments on the HOST over a whole scene: builds the layout tor_scene_upload builds
+// (no float32 segments) and walks its kinds 10 / 11 / 12 for each ray as integrate_kernel's ARITH 2 loop does -- kinds 11 / 12
+// through the plane screen first (the {cx, cz} table, the segment's largest radius^2), then the second form on the 32-byte record;
+// kind 10 through the second form alone.  keep[ray * world.len + object] = 0 dropped by the plane screen, 1 dropped by the second
+// form, 2 a candidate of the exact test, 3 the object is on a first-form segment (a general mover, a mover without a common height).
+// kind_out[object] (nullable) = its segment's kind (0 first form, 10, 11, 12).  No device needed.
+int tor_debug_screen2_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d, const double* time, int8_t* keep,
+                            int32_t* kind_out) {
+  if (world.len < 0 || (world.len > 0 && !world.objects) || n_rays < 0 || !o || !d || !time || !keep)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_screen2_scene: bad argument");
+  std::vector<int64_t> ids((size_t)world.len);
+  for (int64_t i = 0; i < world.len; ++i) ids[(size_t)i] = i;
+  tor::HostLayout lay;
+  std::string err;
+  if (!tor::build_layout(world.objects, ids, lay, err, nullptr)) return fail(TOR_ERR_INVALID_ARGUMENT, err);
+  auto orig_of = [&](size_t slot) {
+    int64_t v;
+    std::memcpy(&v, &lay.cold[16 * slot + 14], 8);
+    return v;
+  };
+  for (int64_t r = 0; r < n_rays; ++r) {
+    int8_t* kr = keep + r * world.len;
+    for (int64_t i = 0; i < world.len; ++i) kr[i] = 3;
+    const double* oo = o + 3 * r; const double* dd = d + 3 * r;
+    const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];  // spheres.nim:30
+    const tor::ScreenRay ray = tor::screen2_ray(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a);
+    const tor::PlaneRay pray = tor::plane_ray(ray);
+    for (int s = 0; s < lay.n_segs; ++s) {
+      const double* sg = &lay.segs[8 * (size_t)s];
+      const double* xs = &lay.xsegs[8 * (size_t)s];
+      const int xkind = (int)xs[0];
+      const int count = (int)sg[2] & 0xffffff, real = count - ((int)sg[2] >> 24), block0 = (int)sg[3];
+      if (r == 0 && kind_out)
+        for (int i = 0; i < real; ++i) kind_out[orig_of((size_t)block0 * tor::kPad + (size_t)i)] = xkind;
+      if (xkind < 10) continue;
+      const double f = xkind == 12 ? (time[r] - sg[4]) / sg[5] : 0.0;  // moving_spheres.nim:42
+      const tor::ScreenSeg ss = tor::screen2_seg(ray, sg[6], sg[7], xs[2], f);
+      const tor::PlaneSeg ps = tor::plane_seg(ray, pray, sg[6], sg[7], f, xs[4]);
+      for (int i = 0; i < real; ++i) {
+        const double* x = &lay.xrec[(size_t)xs[1] + 4 * (size_t)i];
+        int8_t verdict;
+        if (xkind == 10) {
+          verdict = tor::screen2_static(ss, x[0], x[1], x[2], x[3]) < 0 ? 2 : 1;
+        } else {
+          const double* pl = &lay.xpl[(size_t)xs[3] + 2 * (size_t)i];
+          if (!(pl[0] == x[0] && pl[1] == x[1])) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_screen2_scene: the plane table and the records disagree (layout bug)");
+          if (tor::plane_word(ps, pl[0], pl[1]) >= 0) verdict = 0;
+          else verdict = (xkind == 12 ? tor::screen2_movy_y(ss, x[0], x[1], x[2], x[3]) : tor::screen2_static_y(ss, x[0], x[1], x[2])) < 0 ? 2 : 1;
+        }
+        kr[orig_of((size_t)block0 * tor::kPad + (size_t)i)] = verdict;
+      }
+    }
+  }
+  return TOR_OK;
+}
+
 // Float32 slab test of the culling boxes on the HOST (same source as the kernel): ray i against box i.
 // keep[i] = slab_bit32 on the float32 record block_bounds_f32 makes of the box; need[i] = the float64 slab test
 // of the kernel's float64 path on the same box.  Correct iff need implies keep.
