@@ -554,8 +554,12 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
             w_count += 1;
           }
           if (plane_ran) {  // stage two emptied words: the summary again, from the words as they are now
-            nz = 0;
-            for (int k2 = 0; k2 < w_count; ++k2) nz = push_cond(nz, q[(unsigned)k2 * 64] != 0u);
+            // (all kQCap slots are read, back to back -- one LDS latency instead of one per word -- and the slots this pass did
+            // not write, stale words of an earlier query, are shifted out)
+            unsigned all = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < kQCap; ++k2) all = push_cond(all, q[(unsigned)k2 * 64] != 0u);
+            nz = all >> (unsigned)(kQCap - w_count);
           }
         }
         }  // if (active)
