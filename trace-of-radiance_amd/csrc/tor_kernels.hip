@@ -679,7 +679,9 @@ static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? ((p.two_level != 0 && wants_f32(p) != 0) ? 2 : 1) : 0; }
 static size_t dynamic_lds(const KParams& p) {
   return (size_t)wave_lds_bytes(wants_blocks(p), coop_variant(wants_f32(p), wants_blocks(p))) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
-         (size_t)p.bnd32_lds_floats * 4 + (size_t)p.xrec_lds_doubles * 8;
+         (size_t)p.bnd32_lds_floats * 4 +
+         // (the second-form table of stage two: only the ARITH 2 variants -- brute-force layouts behind the screen -- stage it)
+         ((p.screen != 0 && wants_f32(p) == 0 && wants_blocks(p) == 0) ? (size_t)p.xrec_lds_doubles * 8 : (size_t)0);
 }
 
 // arith as the caller asked (0 strict, 1 fused) -> the kernel variant: strict launches of the brute-force layouts run behind
