@@ -56,7 +56,9 @@
 //                                        loop, the arbiter priorities, the per-query set-up), the host-side launchers
 //   kernel/integrate_refill.inc          (A) work distribution + camera ray
 //   kernel/integrate_loop_*.inc          (B) the wave-uniform object loop, one file per segment family:
-//                                        screen2 (ARITH 2 second-form records), f64_static, f64_movers, f32 (TOR_ACCEL_F32),
+//                                        plane (ARITH 2, common-height segments: the plane screen for every object, then the
+//                                        second form per lane on what it keeps -- DESIGN.md 4.14), screen2 (ARITH 2 second-form
+//                                        records, wave-uniform -- 4.12), f64_static, f64_movers, f32 (TOR_ACCEL_F32),
 //                                        boxes32 / boxes64 (TOR_ACCEL_BLOCKS)
 //   kernel/integrate_resolve_lane.inc    exact float64 tests of the candidates, per lane
 //   kernel/integrate_resolve_coop.inc    ... pooled over the wave (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)
