@@ -214,10 +214,12 @@ TOR_HD double screen2_Ky(double cx, double cz, double r2) { return (cx * cx + cz
 // PROOF needs kept:
 //   the reference accepts a root only if disc_ref > 0, which implies D~ = r^2 - dist(c^, line)^2 > -48 u B^2 (above), so with the
 //   exact unit normal n^ of the exact ground track  (n^ . (c_xz - o_xz))^2 <= dist^2 < r^2 + 48 u B^2.  Computed: the components of
-//   n carry the relative error of d~ (3.1 u), so n / |n| deviates from n^ by <= 4.4 u; the constant n . o_xz and the two fused
-//   operations add <= 4 u |n| B:  |s' / |n| - n^ . (c_xz - o_xz)| <= 9 u B, and with |n^ . (..)| <= B
-//   s'^2 / |n|^2 < r^2 + (48 + 19) u B^2;  w2 as computed is |n|^2 (1 + 2.5 u), the threshold's own two roundings 2 u:
-//   s'^2 < (r^2 + 67 u B^2)(1 + 5 u) w2' < (R^2 (1 + 2^-40) + 256 u B^2) w2'.
+//   n carry the relative error of d~ (3.1 u each, so n = n~ + delta with |delta| <= 3.1 u |n~|, n~ the perpendicular of the exactly
+//   normalised direction, |n~| = w); the constant n . o_xz (a product and an fma) and the two fused operations of the chain round
+//   four times, each by <= u x a magnitude <= 2 sqrt(2) w B:  |s' - n~ . (c_xz - o_xz)| <= (3.1 + 9.9) u w B = 13 u w B, and with
+//   |n~ . (..)| = w dist_2D <= w B:   s'^2 < w^2 (r^2 + (48 + 27) u B^2).   w2 as computed is >= w^2 (1 - 8.2 u) (the components'
+//   3.1 u twice, the sum's own rounding), the threshold's sum and product round twice more:
+//   s'^2 < w^2 (r^2 + 75 u B^2) < (R^2 (1 + 2^-40) + 256 u B^2) w2' (1 - 2 u)   since 2^-40 >> 11 u and 256 (1 - 11 u) > 75.
 // c_xz is exact here: statics, and movers whose c1 - c0 has x = z = 0 exactly (group_moves_along_y_only).
 // A ray whose ground track has no direction (w2 < 2^-200: vertical), whose threshold leaves the normal range, or that is wild
 // keeps everything.
