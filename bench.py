@@ -68,7 +68,7 @@ def parse_args():
                          "1920x1080x1000 (default), c4 = configs[3] 3840x2160x4096 (the config BASELINE assigns to 8 GPUs)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seeding", choices=["sample", "pixel"], default="sample")
-    ap.add_argument("--arith", choices=["strict", "fused"], default="strict")
+    ap.add_argument("--arith", choices=["strict"], default="strict", help="(TOR_ARITH_FUSED was removed in round 5)")
     ap.add_argument("--accel", choices=list(ACCEL_BITS), default="none",
                     help="none: the reference's brute-force closest hit (the metric's algorithm); others: exact accelerations")
     ap.add_argument("--row-tile", type=int, default=1,
@@ -268,7 +268,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
     H, W = args.height, args.width
     spp = args.spp if args.spp != 1000 else 256
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
-    arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
+    arith = tor.ARITH_STRICT
     n_steps = args.warmup + args.steps
     anim = tor.Animation(H, W, 0.005, 0.0, 7.2)   # 240 frames at skip 6
     frames = []
@@ -358,7 +358,7 @@ def bench_single_process_multi_device(args, tor):
     scene = tor.random_scene(0xFACADE)
     cam = tor.camera(aspect_ratio=W / H) if (W * 9 != H * 16) else tor.camera()
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
-    arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
+    arith = tor.ARITH_STRICT
     accel = ACCEL_BITS[args.accel]
     opt = tor.make_options(seeding=seeding, arith=arith, accel=accel, row_tile=args.row_tile, devices=devices)
     cv = tor.new_canvas(H, W, spp, 2.2)
@@ -475,7 +475,7 @@ def main():
         return bench_single_process_multi_device(args, tor)
     spp = frame_spp(args, world)  # strong scaling (default): the frame is the same whatever N
     seeding = tor.SEED_SAMPLE if args.seeding == "sample" else tor.SEED_PIXEL
-    arith = tor.ARITH_STRICT if args.arith == "strict" else tor.ARITH_FUSED
+    arith = tor.ARITH_STRICT
     accel = ACCEL_BITS[args.accel]
 
     scene = tor.random_scene(0xFACADE)

@@ -109,8 +109,10 @@ enum {
 
 /* Rounding of the ray/sphere quadratic. */
 enum {
-  TOR_ARITH_STRICT = 0, /* reference operation order, no FMA (README.md:82)               */
-  TOR_ARITH_FUSED = 1   /* same formulas with explicit fma(); throughput variant          */
+  TOR_ARITH_STRICT = 0, /* reference operation order, no FMA (README.md:82) -- the only arithmetic     */
+  TOR_ARITH_FUSED = 1   /* REMOVED in round 5 (rounds 1-4: the same formulas with explicit fma(); not the
+                           reference's rounding, and slower than STRICT behind the conservative screen).  The value
+                           stays reserved: every entry point rejects it with TOR_ERR_INVALID_ARGUMENT and says why. */
 };
 
 /* Exact accelerations of the closest-hit query; a bit mask.  They never change a pixel:

@@ -107,7 +107,9 @@ def test_bad_settings_say_why_before_a_device_is_touched(tor, monkeypatch):
     cv = tor.new_canvas(4, 4, 1, 2.2)
     cv.pixels[:] = 7.0
     for kw, word in ((dict(devices=[0, 0], shard_index=1, shard_count=2), "device list"), (dict(devices=[0, 1], device=5), "device"),
-                     (dict(row_tile=-3), "row_tile"), (dict(accel=9), "accel"), (dict(seeding=5), "seeding")):
+                     (dict(row_tile=-3), "row_tile"), (dict(accel=9), "accel"), (dict(seeding=5), "seeding"),
+                     # round 5: the fused-arithmetic variants are gone; the enum value stays reserved and old callers fail loudly
+                     (dict(arith=tor.ARITH_FUSED), "TOR_ARITH_FUSED was removed"), (dict(arith=2), "arith")):
         with pytest.raises(tor.TorError) as e:
             tor.render(cv, cam, scene.list(), 5, tor.make_options(**kw))
         assert e.value.code == -1 and word in str(e.value), (kw, str(e.value))

@@ -28,7 +28,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtor_mi355x.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 SEED_PIXEL, SEED_SAMPLE = 0, 1
-ARITH_STRICT, ARITH_FUSED = 0, 1
+ARITH_STRICT, ARITH_FUSED = 0, 1   # (ARITH_FUSED: removed in round 5; the library rejects it and says why)
 ACCEL_NONE, ACCEL_BLOCKS, ACCEL_F32 = 0, 1, 2
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 PIXEL_KERNEL_AUTO, PIXEL_KERNEL_LANE, PIXEL_KERNEL_WAVE = 0, 1, 2

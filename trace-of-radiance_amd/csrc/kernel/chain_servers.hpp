@@ -82,7 +82,6 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
   const int lane = threadIdx.x & 63;
   const double w_div = (double)(p.ncols - 1);  // render.nim:64
   const double h_div = (double)(p.nrows - 1);
-  const cdptr cold = as_const(p.cold);
   // this lane's block boxes: records lane and lane + 64 of the float32 boxes (constant for the launch)
   const float nanf_ = __builtin_nanf("");
   f2v bx0 = splat2(nanf_), by0 = bx0, bz0 = bx0, bx1 = bx0, by1 = bx0, bz1 = bx0;
@@ -243,7 +242,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
 #endif
         const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
         const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
-        const double a = (ARITH != 1) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
+        const double a = a_strict;
         const RayF32 r32 = make_ray_f32(ox, oy, oz, dx, dy, dz, a_strict, p.org[0], p.org[1], p.org[2]);
         const BoxRay32 b32 = make_box_ray32(r32, p.sp_bmax, p.sp_hmin);
         const unsigned wild = r32.wild & 1u;  // a ray outside the float32 test's guarded ranges enters every box
@@ -316,20 +315,12 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
             double f = f_sp;  // (the spatial movers share one time group: same operands as the division, same quotient)
             if (moving && !(k7 == p.sp_t0 && k8 == p.sp_dt)) f = (time - k7) / k8;
             double mx, my, mz;  // centre of a mover (moving_spheres.nim:43); a static sphere keeps c0 untouched
-            if (ARITH != 1) { mx = k0 + k3 * f; my = k1 + k4 * f; mz = k2 + k5 * f; }
-            else { mx = fma_(k3, f, k0); my = fma_(k4, f, k1); mz = fma_(k5, f, k2); }
+            mx = k0 + k3 * f; my = k1 + k4 * f; mz = k2 + k5 * f;
             const double cx = moving ? mx : k0, cy = moving ? my : k1, cz = moving ? mz : k2;
             const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-            double hb, cc, disc;
-            if (ARITH != 1) {
-              hb = ocx * dx + ocy * dy + ocz * dz;             // spheres.nim:31
-              cc = (ocx * ocx + ocy * ocy + ocz * ocz) - k15;  // spheres.nim:32
-              disc = hb * hb - a * cc;                         // spheres.nim:33
-            } else {
-              hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
-              cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -k15)));
-              disc = fma_(hb, hb, -(a * cc));
-            }
+            const double hb = ocx * dx + ocy * dy + ocz * dz;             // spheres.nim:31
+            const double cc = (ocx * ocx + ocy * ocy + ocz * ocz) - k15;  // spheres.nim:32
+            const double disc = hb * hb - a * cc;                         // spheres.nim:33
             // both roots are <= 0 when half_b >= 0 and c >= 0: such an object can never be accepted (t_min = 0.001)
             if (disc > 0.0 && (hb < 0.0 || cc < 0.0)) {
               const double root = __builtin_sqrt(disc);  // spheres.nim:35-48

@@ -140,22 +140,15 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
       for (int depth = 0; depth < p.max_depth; ++depth) {
         // ---- closest hit, the object loop split across the lanes (hittables_lists.nim:48-55) ----
         const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
-        const double a = (ARITH == 0) ? dx * dx + dy * dy + dz * dz : fma_(dz, dz, fma_(dy, dy, dx * dx));  // spheres.nim:30
+        const double a = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
         double best_t = __builtin_inf(), best_f = 0.0;
         int best_slot = -1, best_orig = 0x7fffffff;
         // exact test of one object (spheres.nim:28-49) and the order-independent closest-hit update
         auto test_object = [&](int k, double cx, double cy, double cz, double r2, double f) {
           const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-          double hb, cc, disc;
-          if (ARITH == 0) {
-            hb = ocx * dx + ocy * dy + ocz * dz;            // spheres.nim:31
-            cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;  // spheres.nim:32
-            disc = hb * hb - a * cc;                        // spheres.nim:33
-          } else {
-            hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
-            cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
-            disc = fma_(hb, hb, -(a * cc));
-          }
+          const double hb = ocx * dx + ocy * dy + ocz * dz;            // spheres.nim:31
+          const double cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;  // spheres.nim:32
+          const double disc = hb * hb - a * cc;                        // spheres.nim:33
           // both roots are <= 0 when half_b >= 0 and c >= 0: such an object can never be accepted (t_min = 0.001)
           if (disc > 0.0 && (hb < 0.0 || cc < 0.0)) {
             const double root = __builtin_sqrt(disc);  // spheres.nim:35-48
@@ -189,11 +182,9 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
             const double f = g_f;
             double cx = T[0 * 64], cy = T[1 * 64], cz = T[2 * 64];
             if (kind == 1) {  // center1.x == center0.x and center1.z == center0.z: c0 + f * 0 == c0
-              cy = (ARITH == 0) ? cy + T[4 * 64] * f : fma_(T[4 * 64], f, cy);
-            } else if (ARITH == 0) {
-              cx = cx + T[3 * 64] * f; cy = cy + T[4 * 64] * f; cz = cz + T[5 * 64] * f;  // moving_spheres.nim:43
+              cy = cy + T[4 * 64] * f;
             } else {
-              cx = fma_(T[3 * 64], f, cx); cy = fma_(T[4 * 64], f, cy); cz = fma_(T[5 * 64], f, cz);
+              cx = cx + T[3 * 64] * f; cy = cy + T[4 * 64] * f; cz = cz + T[5 * 64] * f;  // moving_spheres.nim:43
             }
             test_object(k, cx, cy, cz, T[8 * 64], f);
           } else {  // mixed trip: per-object kind and time group
@@ -202,8 +193,7 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
             if ((int)__double_as_longlong(T[9 * 64]) & 1) {
               const double t0 = T[6 * 64], dt = T[7 * 64];
               f = (have_group && t0 == g_t0 && dt == g_dt) ? g_f : (time - t0) / dt;
-              if (ARITH == 0) { cx = cx + T[3 * 64] * f; cy = cy + T[4 * 64] * f; cz = cz + T[5 * 64] * f; }
-              else { cx = fma_(T[3 * 64], f, cx); cy = fma_(T[4 * 64], f, cy); cz = fma_(T[5 * 64], f, cz); }
+              cx = cx + T[3 * 64] * f; cy = cy + T[4 * 64] * f; cz = cz + T[5 * 64] * f;
             }
             test_object(k, cx, cy, cz, T[8 * 64], f);
           }
@@ -229,8 +219,7 @@ __global__ __launch_bounds__(kThreads) void coop_pixel_kernel(const KParams p) {
         const int flags = (int)__double_as_longlong(c[13]);
         V3 center = v3(c[0], c[1], c[2]);
         if (flags & 1) {
-          if (ARITH == 0) center = center + v3(c[3], c[4], c[5]) * hit_f;
-          else center = v3(fma_(c[3], hit_f, c[0]), fma_(c[4], hit_f, c[1]), fma_(c[5], hit_f, c[2]));
+          center = center + v3(c[3], c[4], c[5]) * hit_f;
         }
         const V3 hp = o + d * t_min;               // rays.nim:24-25
         const V3 outward = (hp - center) * c[6];   // spheres.nim:43

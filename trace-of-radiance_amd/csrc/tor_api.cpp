@@ -175,7 +175,10 @@ bool valid_options(const TorOptions* opt, TorOptions& o, bool for_drop_in) {
     }
   }
   if (o.seeding != TOR_SEED_PIXEL && o.seeding != TOR_SEED_SAMPLE) return no("seeding must be TOR_SEED_PIXEL or TOR_SEED_SAMPLE");
-  if (o.arith != TOR_ARITH_STRICT && o.arith != TOR_ARITH_FUSED) return no("arith must be TOR_ARITH_STRICT or TOR_ARITH_FUSED");
+  if (o.arith == TOR_ARITH_FUSED)
+    return no("TOR_ARITH_FUSED was removed in round 5: it was not the reference's rounding (README.md:82) and TOR_ARITH_STRICT behind the conservative "
+              "FMA screen is faster -- pass TOR_ARITH_STRICT (0)");
+  if (o.arith != TOR_ARITH_STRICT) return no("arith must be TOR_ARITH_STRICT");
   if (o.accel < 0 || o.accel > (TOR_ACCEL_BLOCKS | TOR_ACCEL_F32)) return no("accel holds unknown TOR_ACCEL_* bits");
   if (o.shard_count < 1) o.shard_count = 1;  // (0 in a zero-initialised struct: whole image, one row per tile)
   if (o.row_tile == 0) o.row_tile = 1;

@@ -47,8 +47,8 @@
 //   finalize_kernel    canvas.nim:47-54 (draw): pow(sum * 1/spp, 1/gamma)
 //   quantize_kernel    io/ppm.nim:15-16
 //
-// float64 throughout, no FMA contraction (-ffp-contract=off); TOR_ARITH_FUSED uses explicit
-// fma() in the discriminant and the moving-sphere centre only.
+// float64 throughout, no FMA contraction (-ffp-contract=off): the only fused operations are the explicit fma() of the
+// conservative screens (tor_screen.hpp, tor_filter32.hpp), whose candidates are all re-tested with the reference's operations.
 //
 // Layout of the source (round 4; the pieces are TEXTUAL includes -- one translation unit, the same code the single file
 // compiled to, checked by comparing the generated ISA):
@@ -102,25 +102,17 @@ __device__ __forceinline__ unsigned long long bcast_first_u64(unsigned long long
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// One ray/object discriminant, strict or fused.  Returns the sign-bit filter word: negative
+// One ray/object discriminant (the reference's unfused operations).  Returns the sign-bit filter word: negative
 // (bit 31 set) iff disc has a clear sign bit (disc >= +0 or NaN+) and (half_b < 0 or c < 0),
 // a superset of the objects the reference's hit() can accept (both roots are <= 0 when
 // half_b >= 0 and c >= 0).  One v_bitop3_b32: f(a,b,c) = (a|b) & ~c  -> truth table 0x54.
-template <int ARITH>
 __device__ __forceinline__ int disc_filter(double ox, double oy, double oz, double dx, double dy,
                                            double dz, double a, double cx, double cy, double cz,
                                            double r2) {
   double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-  double hb, cc, disc;
-  if (ARITH != 1) {
-    hb = ocx * dx + ocy * dy + ocz * dz;          // spheres.nim:31
-    cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;  // spheres.nim:32
-    disc = hb * hb - a * cc;                      // spheres.nim:33
-  } else {
-    hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
-    cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -r2)));
-    disc = fma_(hb, hb, -(a * cc));
-  }
+  const double hb = ocx * dx + ocy * dy + ocz * dz;          // spheres.nim:31
+  const double cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;  // spheres.nim:32
+  const double disc = hb * hb - a * cc;                      // spheres.nim:33
 #if __has_builtin(__builtin_amdgcn_bitop3_b32)
   return (int)__builtin_amdgcn_bitop3_b32((unsigned)hi32(hb), (unsigned)hi32(cc), (unsigned)hi32(disc), 0x54);
 #else
@@ -434,7 +426,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       // (computed by every lane: a lane without a live path works on stale values that nobody reads)
       const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
       const double a_strict = dx * dx + dy * dy + dz * dz;  // spheres.nim:30
-      const double a = (ARITH != 1) ? a_strict : fma_(dz, dz, fma_(dy, dy, dx * dx));
+      const double a = a_strict;
       double best_t = __builtin_inf();
       int best_idx = -1;
       int best_orig = 0x7fffffff;
@@ -653,15 +645,16 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from tor_api.cpp)
 // ---------------------------------------------------------------------------------------
-// variant table: [seeding 0|1][arith 0|1][W 2|3][f32 0|1][blocks 0|1|2 (2: two-level layouts, cooperative variants only)].  The block-expansion code (an unrolled
-// 8-object stage per lane) is what makes the 168-register variants spill; launches without TOR_ACCEL_BLOCKS
-// use kernels compiled without it (no scratch traffic at all).
+// variant table: [seeding 0|1|2 (2: the cost probe)][arith 0 | 2 (2: behind the FMA screen, brute-force layouts only)][W 2|3][f32 0|1]
+// [blocks 0|1|2 (2: two-level layouts, cooperative variants only)].  The block-expansion code (an unrolled 8-object stage per lane)
+// is what makes the 168-register variants spill; launches without TOR_ACCEL_BLOCKS use kernels compiled without it (no scratch
+// traffic at all).  (Round 5: the 20 TOR_ARITH_FUSED instantiations -- `arith 1`, not the reference's rounding -- are gone.)
 typedef void (*IntegrateFn)(const KParams);
 static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32, int blocks) {
 #define TOR_V(S, A, W, F, B) if (seeding == S && arith == A && w == W && f32 == F && blocks == B) return integrate_kernel<S, A, W, F, B>;
 #define TOR_V4(S, A, W) TOR_V(S, A, W, 0, 0) TOR_V(S, A, W, 0, 1) TOR_V(S, A, W, 1, 0) TOR_V(S, A, W, 1, 1) TOR_V(S, A, W, 1, 2)
-  TOR_V4(0, 0, 2) TOR_V4(0, 1, 2) TOR_V4(1, 0, 2) TOR_V4(1, 1, 2)
-  TOR_V4(0, 0, 3) TOR_V4(0, 1, 3) TOR_V4(1, 0, 3) TOR_V4(1, 1, 3)
+  TOR_V4(0, 0, 2) TOR_V4(1, 0, 2)
+  TOR_V4(0, 0, 3) TOR_V4(1, 0, 3)
   TOR_V4(2, 0, 3)   // cost probe of the SEED_PIXEL tile schedule
   // arith 2: the reference's arithmetic behind the conservative FMA screen (brute-force layouts only)
   TOR_V(0, 2, 2, 0, 0) TOR_V(0, 2, 3, 0, 0) TOR_V(1, 2, 2, 0, 0) TOR_V(1, 2, 3, 0, 0) TOR_V(2, 2, 3, 0, 0)
@@ -686,10 +679,10 @@ static size_t dynamic_lds(const KParams& p) {
          ((p.screen != 0 && wants_f32(p) == 0 && wants_blocks(p) == 0) ? (size_t)p.xrec_lds_doubles * 8 : (size_t)0);
 }
 
-// arith as the caller asked (0 strict, 1 fused) -> the kernel variant: strict launches of the brute-force layouts run behind
-// the conservative FMA screen (variant 2: the same canvas bit for bit) unless the context turned it off (KParams::screen)
+// the kernel variant of a launch: the brute-force layouts run behind the conservative FMA screen (variant 2: the same canvas
+// bit for bit) unless the context turned it off (KParams::screen); `arith` is TOR_ARITH_STRICT (0), the only arithmetic there is
 static int arith_variant(const KParams& p, int arith) {
-  return (arith == 0 && p.screen != 0 && wants_f32(p) == 0 && wants_blocks(p) == 0) ? 2 : arith;
+  return (arith == 0 && p.screen != 0 && wants_f32(p) == 0 && wants_blocks(p) == 0) ? 2 : 0;
 }
 
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
@@ -740,13 +733,15 @@ size_t coop_lds_bytes(int coop_slots) { return (size_t)kCoopArrays * 8 * (size_t
 
 int coop_blocks_per_cu(const KParams& p, int arith) {
   int n = 0;
-  auto fn = arith ? coop_pixel_kernel<1> : coop_pixel_kernel<0>;
+  (void)arith;
+  auto fn = coop_pixel_kernel<0>;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, coop_lds_bytes(p.coop_slots)) != hipSuccess) n = 0;
   return n;
 }
 
 hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream) {
-  auto fn = arith ? coop_pixel_kernel<1> : coop_pixel_kernel<0>;
+  (void)arith;
+  auto fn = coop_pixel_kernel<0>;
   const size_t lds = coop_lds_bytes(p.coop_slots);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
