@@ -160,11 +160,25 @@ def pmc_child(spec):
     print("pmc-child done", float(cv.pixels.mean()))
 
 
-def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=240, shard=(0, 1, 1)):
-    """HBM bytes of ONE integrate_kernel launch of this configuration, from two separate rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots'), corrected as the
-    guide's HBM section says: FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE is
-    taken as is (uncalibrated); both are reported in KiB by rocprofv3.  None when rocprofv3 is missing or fails."""
+# rocprofv3 --pmc passes of the live measurement.  FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md "rocprofv3
+# PMC slots"); the SQ instruction counters fit one pass of eight (tools/profile_gpu.sh runs the same groups); GRBM_GUI_ACTIVE --
+# the denominator of the issue utilisation -- gets its own, as in the committed summaries.
+PMC_PASSES = (
+    ("FETCH_SIZE",),
+    ("WRITE_SIZE",),
+    ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"),
+    ("GRBM_GUI_ACTIVE",),
+)
+PEAK_FP64_ISSUE_TLANEOPS = 39.3   # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: float64 lane-operations per second (an FMA is ONE), datasheet clock
+SIMDS, XCDS = 1024, 8
+
+
+def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=240, shard=(0, 1, 1), sq=True):
+    """Counters of ONE integrate_kernel launch of this configuration, from separate rocprofv3 --pmc passes around a child
+    process (PMC_PASSES): HBM bytes -- FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE as is
+    (uncalibrated), both in KiB, as the guide's HBM section says -- and, with sq=True, the executed-instruction view (VALU /
+    float64 wave-instructions, VALU-active quad-cycles, GPU-active cycles).  None when rocprofv3 is missing or a traffic pass
+    fails; a failing SQ pass only drops the `executed` block (its reason is kept)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -174,35 +188,85 @@ def live_traffic(W, H, spp, depth, seeding, arith, accel, timeout_s=240, shard=(
     base = tempfile.mkdtemp(prefix="tor_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", TOR_NO_TORCH="1")
     spec = f"{W},{H},{spp},{depth},{seeding},{arith},{accel},{shard[0]},{shard[1]},{shard[2]}"
+    t_all = time.perf_counter()
+    sq_note = None
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(base, counter)
-            r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                                "--pmc-child", spec], capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} failed: {r.stderr[-300:]}"
-            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
-            if not dbs:
-                return None, f"rocprofv3 --pmc {counter}: no rocpd database"
-            con = sqlite3.connect(dbs[0])
-            rows = con.execute("select name, sum(counter_value), max(duration), dispatch_id from pmc_events where counter_name = ? "
-                               "group by name, dispatch_id order by dispatch_id", (counter,)).fetchall()
-            rows = [r_ for r_ in rows if "integrate_kernel" in r_[0]]
-            if not rows:
-                return None, f"rocprofv3 --pmc {counter}: no integrate_kernel dispatch in the database"
-            longest = max(r_[2] for r_ in rows)
-            best = [r_ for r_ in rows if r_[2] >= 0.5 * longest][-1]   # the LAST frame launch (the 2-spp cost probes are tiny)
-            out[counter] = float(best[1])
-            out[counter + "_kernel_ms"] = float(best[2]) / 1e6
+        for n_pass, counters in enumerate(PMC_PASSES):
+            traffic_pass = counters[0] in ("FETCH_SIZE", "WRITE_SIZE")
+            if not traffic_pass and not sq:
+                continue
+            d = os.path.join(base, f"pass{n_pass}")
+            try:
+                r = subprocess.run([exe, "--pmc", *counters, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                                    "--pmc-child", spec], capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+                why = None if r.returncode == 0 else f"rocprofv3 --pmc {' '.join(counters)} failed: {r.stderr[-300:]}"
+            except subprocess.TimeoutExpired:
+                why = f"rocprofv3 --pmc {' '.join(counters)}: no result after {timeout_s} s"
+            rows = []
+            if why is None:
+                dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+                if not dbs:
+                    why = f"rocprofv3 --pmc {counters[0]}: no rocpd database"
+                else:
+                    con = sqlite3.connect(dbs[0])
+                    rows = con.execute("select name, counter_name, sum(counter_value), max(duration), dispatch_id from pmc_events "
+                                       "group by name, counter_name, dispatch_id order by dispatch_id").fetchall()
+                    rows = [r_ for r_ in rows if "integrate_kernel" in r_[0]]
+                    if not rows:
+                        why = f"rocprofv3 --pmc {counters[0]}: no integrate_kernel dispatch in the database"
+            if why is not None:
+                if traffic_pass:
+                    return None, why
+                sq_note = why
+                continue
+            longest = max(r_[3] for r_ in rows)
+            last = [r_ for r_ in rows if r_[3] >= 0.5 * longest][-1][4]   # the LAST frame launch (the 2-spp cost probes are tiny)
+            for r_ in rows:
+                if r_[4] == last:
+                    out[r_[1]] = float(r_[2])
+                    out[r_[1] + "_kernel_ms"] = float(r_[3]) / 1e6
+                    out["kernel"] = r_[0]
     except Exception as e:  # noqa
         return None, f"live PMC pass failed: {e!r}"
     finally:
         shutil.rmtree(base, ignore_errors=True)
     out["bytes"] = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
-    out["what"] = ("second of two identical launches in a child process (steady state); FETCH_SIZE doubled (gfx950), WRITE_SIZE as is: "
-                   "for SEED_SAMPLE it is the float64 flush atomics -- each 8-byte atomic is one 32-byte write request at the fabric -- "
-                   "plus the write-back of the canvas clear (profiles/r3_traffic_reconcile.txt)")
+    out["pmc_seconds"] = round(time.perf_counter() - t_all, 1)
+    out["what"] = ("second of two identical launches in a child process (steady state), one rocprofv3 --pmc pass per counter group; "
+                   "FETCH_SIZE doubled (gfx950), WRITE_SIZE as is: for SEED_SAMPLE it is the float64 flush atomics -- each 8-byte atomic "
+                   "is one 32-byte write request at the fabric -- plus the write-back of the canvas clear (profiles/r3_traffic_reconcile.txt)")
+    if sq_note:
+        out["executed_note"] = sq_note
     return out, None
+
+
+def executed_from_counters(c, samples):
+    """The executed-instruction view of one launch from live_traffic()'s SQ / GRBM counters (`samples` = the pixel-samples that
+    launch traced).  Wave-instruction counts x 64 lanes = lane-operations; an FMA counts ONCE against the ISSUE peak (39.3 T/s)
+    and twice in executed_tflops (78.6 peak).  SQ_ACTIVE_INST_VALU is in quad-cycles (x 4 = SIMD cycles with a VALU instruction
+    in flight); GRBM_GUI_ACTIVE, summed over the 8 XCDs, / 8 = GPU-active cycles, x 1024 SIMDs = the SIMD cycles there were."""
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")
+    if not c or any(k not in c for k in need):
+        return None
+    k_s = c["SQ_INSTS_VALU_kernel_ms"] * 1e-3
+    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+    lane_ops = f64 * 64.0 / k_s
+    simd_cycles = c["GRBM_GUI_ACTIVE"] / XCDS * SIMDS
+    clock_ghz = c["GRBM_GUI_ACTIVE"] / XCDS / (c["GRBM_GUI_ACTIVE_kernel_ms"] * 1e-3) / 1e9
+    return {
+        "source": "measured in this run (rocprofv3 --pmc around one launch of the same configuration, child process)",
+        "kernel": c.get("kernel"), "kernel_ms": round(c["SQ_INSTS_VALU_kernel_ms"], 3),
+        "valu_wave_instructions": c["SQ_INSTS_VALU"], "fp64_wave_instructions": f64,
+        "fp64_fma_wave_instructions": c["SQ_INSTS_VALU_FMA_F64"],
+        "salu_wave_instructions": c.get("SQ_INSTS_SALU"), "lds_wave_instructions": c.get("SQ_INSTS_LDS"),
+        "valu_per_sample": round(c["SQ_INSTS_VALU"] * 64.0 / samples, 1), "fp64_per_sample": round(f64 * 64.0 / samples, 1),
+        "fp64_lane_ops_per_s": lane_ops, "frac_fp64_issue": round(lane_ops / (PEAK_FP64_ISSUE_TLANEOPS * 1e12), 4),
+        "executed_tflops": round((f64 + c["SQ_INSTS_VALU_FMA_F64"]) * 64.0 / k_s / 1e12, 3),
+        "valu_issue_util": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 4),
+        "gpu_clock_ghz": round(clock_ghz, 3),
+        "formulae": "frac_fp64_issue = (ADD + MUL + FMA float64 wave-instructions) x 64 / kernel time / 39.3e12; valu_issue_util = "
+                    "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+    }
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -416,6 +480,10 @@ def bench_single_process_multi_device(args, tor):
     roof["traffic"] = traffic["bytes"] if traffic else None
     roof["traffic_detail"] = traffic if traffic else traffic_note
     roof["traffic_scope"] = f"one launch = shard 0 of {N} ({shard_rows[0]} rows)"
+    roof["executed_live"] = executed_from_counters(traffic, shard_rows[0] * W * spp)
+    roof["frac_executed"] = roof["executed_live"]["frac_fp64_issue"] if roof["executed_live"] else None
+    roof["note"] = ("frac_executed / executed_live (counters of one shard's launch, read in this run) are fractions of a roof; frac is SURVEY 8(d)'s "
+                    "reference-formulation operation count over the FMA peak and exceeds 1 by design")
     roof["hbm"] = {"bound": "hbm", "algorithmic_bytes_per_launch": shard_rows[0] * W * 24.0 * (2 if seeding == tor.SEED_SAMPLE else 1) + 64e3,
                    "peak": PEAK_HBM_GBPS, "unit": "GB/s"}
     if per_dev and per_dev[0] > 0:
@@ -432,7 +500,7 @@ def bench_single_process_multi_device(args, tor):
                                   f"device contexts, framebuffer gather inside the library ({note})",
                    "timed_region": "SURVEY 8(d): host canvas in/out (scene cached after the first call)"},
         "gather": {"leg": info["leg"], "rccl_ranks": info["rccl_ranks"], "devices": info["devices"], "distinct_gpus": n_distinct, "note": note},
-        "rccl_ranks": info["rccl_ranks"],
+        "gather_leg": info["leg"], "rccl_ranks": info["rccl_ranks"],
         "single_gpu_same_run": {"value": round(n1_value, 2), "unit": "Msamples/s", "steps": aux, "ms_per_step": round(dt1 / aux * 1e3, 3),
                                 "speedup": round(value / n1_value, 3), "region": "the same frame and region on devices[0] alone"},
         "last_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
@@ -687,19 +755,28 @@ def main():
             "scope": "per GPU (achieved and peak are one device's; N > 1: the frame's samples / N over the slowest rank's kernel time)",
             "traffic": traffic["bytes"] if traffic else None,
             "traffic_detail": traffic if traffic else traffic_note,
-            "executed_live": live,
+            "workload_live": live,
+            # the EXECUTED-instruction view, measured in this run (the SQ / GRBM passes of live_traffic): the fraction of a roof that
+            # `frac` -- the reference formulation's operation count over the kernel time, > 1 since the screens -- no longer is
+            "executed_live": executed_from_counters(traffic, local_samples) if world == 1 else None,
             "from_profile": from_profile(W, H, spp, args.seeding, args.arith, args.accel) if world == 1 else None,
             "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 4), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 8),
                     "algorithmic_bytes_per_launch": hbm_bytes},
-            "note": "the path is float64-VALU bound by design (scene in SGPRs via the scalar cache, 24 B of HBM per pixel).  achieved = "
-                    "samples/s x the reference formulation's float64 operation count (SURVEY 8d).  The reference's arithmetic has no FMA "
+            "note": "WHICH NUMBER IS A FRACTION OF A ROOF: `frac_executed` (= executed_live.frac_fp64_issue: float64 lane-operations the "
+                    "kernel really issued per second over the 39.3 T/s float64 issue peak) and executed_live.valu_issue_util (share of the SIMD "
+                    "cycles with a VALU instruction in flight), both from counters read in this run.  `frac` is SURVEY 8(d)'s figure -- samples/s x "
+                    "the operations the REFERENCE's formulation would spend (41.9 k per sample, nothing hoisted or fused) over the FMA peak -- "
+                    "which the survey itself says exceeds 1 once work is removed; it prices the throughput in the reference's units, it is "
+                    "not a utilisation.  The path is float64-VALU bound by design (scene in SGPRs via the scalar cache, 24 B of HBM per pixel).  "
+                    "The reference's arithmetic has no FMA "
                     "(0.5 of the FMA peak would be its ceiling); the object loop therefore SCREENS every ray x object pair with a "
                     "conservative float64 FMA form of the same geometry (csrc/tor_screen.hpp: 4 instructions per object for the distance to the "
                     "vertical plane through the ray, then the expanded quadratic -- 7 to 10 -- on the ~9 objects per query that keeps) and runs "
                     "the reference's unfused operations only on the candidates -- same canvas bit for bit (`unscreened` = without any of "
                     "it, `second_form_only` = without the plane stage)",
         }
+        roof["frac_executed"] = roof["executed_live"]["frac_fp64_issue"] if roof.get("executed_live") else None
         if args.accel != "none":
             # with an exact acceleration the rate is still quoted against the reference's brute-force
             # float64 operation count, so frac can exceed 1
@@ -732,6 +809,9 @@ def main():
         if world > 1:
             result["rccl_ranks"] = rccl_ranks
             result["gather"] = {"kind": gather_kind, "rccl_ranks": rccl_ranks, "world": world}
+            # at a glance: which leg moved the shards -- "rccl" = the library's own communicator (send/recv gather
+            # inside libtor_mi355x), "torch" = the fall-back through torch.distributed's all_gather (RCCL as well under the nccl backend)
+            result["gather_leg"] = "rccl" if (gather_kind or "").startswith("tor_render_gather_device") else "torch"
             if n1 is not None:
                 n1["speedup"] = round(value / n1["value"], 3)
                 result["single_gpu_same_run"] = n1
@@ -845,6 +925,8 @@ def main():
         result["roofline"]["traffic"] = traffic["bytes"] if traffic else None
         result["roofline"]["traffic_detail"] = traffic if traffic else traffic_note
         result["roofline"]["traffic_scope"] = f"one launch = rank 0's shard ({len(my_rows)} of {H} rows)"
+        result["roofline"]["executed_live"] = executed_from_counters(traffic, local_samples)
+        result["roofline"]["frac_executed"] = result["roofline"]["executed_live"]["frac_fp64_issue"] if result["roofline"]["executed_live"] else None
     if rank == 0:
         # (N > 1: after the process group is gone -- the other ranks have left, the host cores are free again)
         result["cpu_baseline"] = (cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds) if not args.no_cpu_baseline

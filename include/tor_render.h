@@ -444,12 +444,14 @@ TOR_API int tor_debug_accel_layout(TorHittableList world, double t_lo, double t_
 TOR_API int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d,
                                      const double* time, int8_t* keep);
 
-/* The strict brute-force layout's second-form segments over a whole scene on the HOST (csrc/tor_screen.hpp; the layout
- * tor_scene_upload builds, walked as the ARITH 2 object loop walks it: plane screen, then second form).
- * keep[ray * world.len + object] = 0 dropped by the plane screen, 1 dropped by the second form, 2 candidate of the exact test,
- * 3 the object sits on a first-form segment; kind_out[object] (nullable) = 0 | 10 | 11 | 12, its segment's kind. */
+/* The strict brute-force layout's screened segments over a whole scene on the HOST (csrc/tor_screen.hpp; the layout
+ * tor_scene_upload builds, walked as the ARITH 2 object loop walks it when stage one runs: plane screen, then the segment's own
+ * test per object -- second form for xkind 10 / 11 / 12, first form for 13 / 14).
+ * keep[ray * world.len + object] = 0 dropped by the plane screen, 1 dropped by stage two, 2 candidate of the exact test,
+ * 3 the object sits on a segment without a plane table; kind_out[object] (nullable) = 0 | 10..14, its segment's xkind;
+ * pays_out[ray * n_segs_out + segment] (nullable) = 1 when that ray votes for stage one on that segment (plane_pays). */
 TOR_API int tor_debug_screen2_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d,
-                                    const double* time, int8_t* keep, int32_t* kind_out);
+                                    const double* time, int8_t* keep, int32_t* kind_out, int8_t* pays_out, int64_t n_segs_out);
 
 /* Float32 slab test of the culling boxes on the HOST (same source as the kernel): ray i against the box [lo_i, hi_i].
  * keep[i] = the float32 test keeps the box, need[i] = the float64 slab test of the float64 path passes.

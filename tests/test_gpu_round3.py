@@ -32,9 +32,12 @@ def _exact(got, want):
 def _render_with_env(tor, scene, cam, h, w, spp, env, depth=50, **opt):
     """One frame through a FRESH context created under `env` (the library's knobs are read at tor_context_create)."""
     import torch
-    saved = {k: os.environ.get(k) for k in HANDOFF_KNOBS}
+    # (every knob this helper may set is restored afterwards -- round 5: a key of `env` outside HANDOFF_KNOBS used to leak into
+    # the contexts created later in the same process, e.g. TOR_PLANE=0 into the run that was meant to be the default)
+    keys = tuple(HANDOFF_KNOBS) + ("TOR_PLANE",) + tuple(k for k in env if k not in HANDOFF_KNOBS)
+    saved = {k: os.environ.get(k) for k in keys}
     try:
-        for k in HANDOFF_KNOBS:
+        for k in keys:
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx = tor.Context(0)

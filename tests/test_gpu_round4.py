@@ -5,7 +5,7 @@
  * the hand-off's stall escape: waiting servers that see no progress flag the frame, the blocking entry points render it again;
  * canvas gamma other than 2.2 (canvas.nim:47-54) in both stream modes, pow_pos device == oracle on those exponents;
  * per-sample streams of configs[2] rows against the pinned LIBM oracle;
- * the plane screen in front of the FMA screen's second form: same canvas, same candidates (TOR_PLANE, TOR_PLANE_LDS)."""
+ * the plane screen in front of the FMA screen's second form: same canvas, same candidates (TOR_PLANE)."""
 import os
 import shutil
 import subprocess
@@ -262,7 +262,8 @@ def test_plane_screen_never_changes_a_pixel_nor_a_candidate(tor, oracle, ref_sce
     EXACTLY what the second form alone leaves.  TOR_PLANE=0 is that second form on every object: same canvas bit for bit and
     the same number of candidates in the resolve pass -- on the screen test's four scenes, on a 700-object scene with segments of
     awkward sizes at several heights (two passes of the candidate words, words shared by two segments), on a frame of the
-    1601-object animation, both stream layouts, records from LDS and through the vector cache; == the oracle."""
+    1601-object animation (its table does not fit the LDS: records through the vector cache), both stream layouts, gated
+    (default) and on every segment (TOR_PLANE=2; round 5: the TOR_PLANE_LDS switch is gone); == the oracle."""
     import torch
     from test_gpu_round3 import _render_with_env, _screen_scenes
     rng = np.random.default_rng(77)
@@ -275,8 +276,8 @@ def test_plane_screen_never_changes_a_pixel_nor_a_candidate(tor, oracle, ref_sce
             off, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {"TOR_PLANE": "0"}, seeding=seeding, accel=0)
             on, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {}, seeding=seeding, accel=0)
             assert torch.equal(on, off), (name, seeding, int((on != off).sum()))
-            vec, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {"TOR_PLANE_LDS": "0"}, seeding=seeding, accel=0)
-            assert torch.equal(vec, off), (name, seeding, "records through the vector cache")
+            vec, _ = _render_with_env(tor, scene, cam, 108, 192, 16, {"TOR_PLANE": "2"}, seeding=seeding, accel=0)
+            assert torch.equal(vec, off), (name, seeding, "stage one on every segment that carries a table (no gate)")
             assert float(on.abs().sum()) > 0.0
     objs, _ = ref_scene
     h, w, spp = 90, 160, 32
@@ -287,7 +288,7 @@ def test_plane_screen_never_changes_a_pixel_nor_a_candidate(tor, oracle, ref_sce
     # candidates of the resolve pass: identical with and without stage one
     for name, scene, cam in (scenes[0], scenes[4]):
         stats = {}
-        for key, env in (("second form", {"TOR_PLANE": "0"}), ("plane + second form", {}), ("records not in LDS", {"TOR_PLANE_LDS": "0"})):
+        for key, env in (("second form", {"TOR_PLANE": "0"}), ("plane + second form", {}), ("records not in LDS", {"TOR_PLANE": "2"})):
             with _env(**env):
                 ctx = tor.Context(0)
             ctx.upload(scene.list())

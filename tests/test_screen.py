@@ -45,6 +45,11 @@ def test_screen_never_drops_a_needed_object(tor, scale, r_lo, r_hi, origin):
     missed = np.flatnonzero((need3 != 0) & (keep3 == 0))
     assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]], c0[missed[:1]], dcy[missed[:1]], f[missed[:1]])
     assert np.array_equal(need3, need2)
+    # round 5: stage one for movers in GENERAL position (xkind 13: the centre's x and z travel too, evaluated inside the chain)
+    keep4, need4 = tor.selftest_screen2(o, d, c0, dc, moving, f, r2, 2)
+    missed = np.flatnonzero((need4 != 0) & (keep4 == 0))
+    assert missed.size == 0, (missed[:5], o[missed[:1]], d[missed[:1]], c0[missed[:1]], dc[missed[:1]], f[missed[:1]])
+    assert np.array_equal(need4, need) and np.count_nonzero(need4) > n // 10
 
 
 def test_screen_on_the_decision_boundary(tor):
@@ -168,6 +173,13 @@ def test_plane_screen_on_its_own_boundary(tor):
     keep, need = tor.selftest_screen2(o, d, c0 - dcm * fm[:, None], dcm, np.ones(n, dtype=np.int32), fm, r * r, 2)
     assert np.count_nonzero((need != 0) & (keep == 0)) == 0
     assert 0 < np.count_nonzero(need) < n
+    # round 5: ... and as movers in GENERAL position caught at f (xkind 13): the ground projection of the centre moves, the chain
+    # evaluates c0_xz + f dc_xz itself (centre = c0 - f dc + f dc up to the rounding of the products, so the rays sit on the boundary
+    # to within a few ulps of the scene size instead of one)
+    dcg = np.column_stack([rng.uniform(-0.7, 0.7, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.7, 0.7, n)])
+    keep, need = tor.selftest_screen2(o, d, c0 - dcg * fm[:, None], dcg, np.ones(n, dtype=np.int32), fm, r * r, 2)
+    assert np.count_nonzero((need != 0) & (keep == 0)) == 0
+    assert 0 < np.count_nonzero(need) < n
     # near-vertical rays through the sphere: the ground track degenerates
     m = 50_000
     c1 = np.column_stack([rng.uniform(-11, 11, m), np.full(m, 0.2), rng.uniform(-11, 11, m)])
@@ -211,8 +223,20 @@ def test_strict_layout_walk_on_the_host(tor):
                 extra.append([1, x, y, z, x + .3, y, z - .2, t0, t1, r, 0, .5, .5, .5, 0, 0])
     add(41, 0.2, 0); add(7, 0.9, 0); add(19, 0.4, 0); add(53, 0.2, 1); add(12, 0.4, 1, 0.25, 0.75); add(5, 0.3, 1); add(9, 0.2, 2)
     extra.append([0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0])
-    mixed = np.asarray(extra, dtype=np.float64)[rng.permutation(len(extra))]
-    for recs_k, want_kinds in ((recs, {10, 11, 12}), (mixed, {0, 10, 11, 12})):
+    n_sane = len(extra)
+    add(3, 0.5, 1, 0.5, 0.5)          # time0 == time1: the time fraction is never finite -> no table (xkind 0), the first form alone
+    mixed = np.asarray(extra, dtype=np.float64)
+    mixed = mixed[rng.permutation(len(mixed))]
+    # third scene (round 5): nothing in common -- a 3-D cloud, every height and radius different, a third static, a third moving
+    # along y, a third moving anywhere
+    cloud = [[0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0]]
+    for i in range(240):
+        x, z = rng.uniform(-8, 8, 2); y = rng.uniform(0.2, 6.0); r = rng.uniform(0.12, 0.3)
+        if i % 3 == 0: cloud.append([0, x, y, z, x, y, z, 0, 1, r, 0, .5, .5, .5, 0, 0])
+        elif i % 3 == 1: cloud.append([1, x, y, z, x, y + rng.uniform(0, .5), z, 0.0, 1.0, r, 0, .5, .5, .5, 0, 0])
+        else: cloud.append([1, x, y, z, x + rng.uniform(-.4, .4), y + rng.uniform(-.3, .3), z + rng.uniform(-.4, .4), 0.0, 1.0, r, 0, .5, .5, .5, 0, 0])
+    cloud = np.asarray(cloud, dtype=np.float64)
+    for recs_k, want_kinds in ((recs, {10, 11, 12}), (mixed, {0, 10, 11, 12, 13, 14}), (cloud, {10, 13, 14})):   # (mixed: the 5 movers along y at 0.3 are below a segment's 8 -> xkind 14)
         scene = tor.Scene.from_records(recs_k)
         n_obj = len(recs_k)
         n_rays = 400
@@ -226,12 +250,17 @@ def test_strict_layout_walk_on_the_host(tor):
         d[aim] = (tgt - o)[aim]
         d[:4] = [[0, -1, 0], [0, 1, 0], [1e-200, -1, 0], [0, -1, 1e-40]]   # vertical: no ground track
         t = rng.uniform(-0.2, 1.2, n_rays)
-        keep, kind = tor.debug_screen2_scene(scene.list(), o, d, t)
+        keep, kind, pays = tor.debug_screen2_scene(scene.list(), o, d, t, max_segs=16)
         assert set(np.unique(kind)) == want_kinds, np.unique(kind)
         is_static = recs_k[:, 0] == 0
         y_mover = (~is_static) & (recs_k[:, 4] == recs_k[:, 1]) & (recs_k[:, 6] == recs_k[:, 3])
-        assert np.all(kind[~is_static & ~y_mover] == 0) and np.all(np.isin(kind[is_static], (10, 11))) and np.all(np.isin(kind[y_mover], (0, 12)))
+        degenerate = (~is_static) & (recs_k[:, 7] == recs_k[:, 8])
+        assert np.all(kind[degenerate] == 0) and np.all(kind[~degenerate] >= 10)
+        assert np.all(kind[~is_static & ~y_mover & ~degenerate] == 13) and np.all(np.isin(kind[is_static], (10, 11)))
+        assert np.all(np.isin(kind[y_mover & ~degenerate], (12, 14)))
         assert np.all((keep == 3) == (kind == 0)[None, :])
+        assert np.all(pays[4:, 0] >= 0)                                # a vote per ray and segment
+        assert np.all(pays[:4][pays[:4] >= 0] == 0)                    # vertical rays keep everything: they vote against stage one
         # need: the reference's own test per pair
         R, O = np.meshgrid(np.arange(n_rays), np.arange(n_obj), indexing="ij")
         R, O = R.ravel(), O.ravel()
@@ -243,6 +272,7 @@ def test_strict_layout_walk_on_the_host(tor):
         on_second_form = keep != 3
         assert np.count_nonzero(need & on_second_form) > 100
         assert np.all(keep[need & on_second_form] == 2), np.argwhere(need & on_second_form & (keep != 2))[:5]
-        plane_segments = np.isin(kind, (11, 12))[None, :] & on_second_form
+        small = np.abs(recs_k[:, 9]) < 5.0                             # (the ground sphere's band is the whole scene)
+        plane_segments = (np.isin(kind, (10, 11, 12, 13, 14)) & small)[None, :] & on_second_form
         assert np.count_nonzero(keep[plane_segments] == 0) > 0.8 * np.count_nonzero(plane_segments)   # most pairs end at stage one
         assert np.all(keep[:4][plane_segments[:4]] >= 1)            # vertical rays: the plane screen keeps everything

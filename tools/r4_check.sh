@@ -6,7 +6,7 @@ mkdir -p gpurun_out/chk
 python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/chk/bench_c3.json').read().strip().splitlines()[-1])
-print('VALUE', d['value'], d['ms_per_step'], d['roofline']['executed_live']['candidates_per_query'])
+print('VALUE', d['value'], d['ms_per_step'], d['roofline']['workload_live']['candidates_per_query'])
 for k in ("unscreened","accel_f32","accel_blocks","accel_blocks_f32","pixel_seeding","pixel_seeding_default_accel"):
     if k in d: print(k, d[k]['value'], {kk:vv for kk,vv in d[k].items() if 'identical' in kk})
 PY

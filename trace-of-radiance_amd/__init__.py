@@ -185,7 +185,9 @@ def lib():
             import torch  # noqa: F401
         except Exception:
             pass
-    L = C.CDLL(LIB_PATH)
+    # (harness-side A/B switch of the tools: TOR_AB_LIB = another build of THIS library -- e.g. last round's kernels -- to measure
+    # against in the same gpurun call; never a fallback: unset, the in-tree library above is the only one there is)
+    L = C.CDLL(os.environ.get("TOR_AB_LIB") or LIB_PATH)
     dp = C.POINTER(C.c_double)
     L.tor_last_error.restype = C.c_char_p
     L.tor_version.restype = C.c_char_p
@@ -241,7 +243,7 @@ def lib():
         [C.POINTER(C.c_double)] * 2 + [C.c_int32] + [C.POINTER(C.c_int32)] * 2
     L.tor_selftest_slab32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int32)] * 2
     L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
-    L.tor_debug_screen2_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
+    L.tor_debug_screen2_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8), C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.c_int64]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -768,17 +770,20 @@ def debug_filter32_scene(world: HittableList, o, d, time):
     return keep
 
 
-def debug_screen2_scene(world: HittableList, o, d, time):
-    """(keep[n_rays, n_objects] int8, kind[n_objects] int32): the strict layout's second-form segments walked on the host --
-    0 dropped by the plane screen, 1 dropped by the second form, 2 candidate, 3 first-form segment; kind 0 | 10 | 11 | 12."""
+def debug_screen2_scene(world: HittableList, o, d, time, max_segs: int = 0):
+    """(keep[n_rays, n_objects] int8, kind[n_objects] int32 [, pays[n_rays, max_segs] int8]): the strict layout's screened
+    segments walked on the host -- 0 dropped by the plane screen, 1 dropped by stage two, 2 candidate, 3 no plane table; kind
+    0 | 10..14; pays (with max_segs > 0): the rays' votes for stage one per segment (plane_pays)."""
     dp = lambda x: np.ascontiguousarray(x, dtype=np.float64)
     o, d, time = dp(o), dp(d), dp(time)
     keep = np.zeros((len(time), int(world.len)), dtype=np.int8)
     kind = np.zeros(int(world.len), dtype=np.int32)
+    pays = np.full((len(time), max(max_segs, 1)), -1, dtype=np.int8)
     P = C.POINTER(C.c_double)
     _check(lib().tor_debug_screen2_scene(world, len(time), o.ctypes.data_as(P), d.ctypes.data_as(P), time.ctypes.data_as(P),
-                                         keep.ctypes.data_as(C.POINTER(C.c_int8)), kind.ctypes.data_as(C.POINTER(C.c_int32))))
-    return keep, kind
+                                         keep.ctypes.data_as(C.POINTER(C.c_int8)), kind.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         pays.ctypes.data_as(C.POINTER(C.c_int8)) if max_segs > 0 else None, max_segs))
+    return (keep, kind, pays) if max_segs > 0 else (keep, kind)
 
 
 def selftest_math(op: int, x: np.ndarray, y: np.ndarray | None = None, where: str = "device", device: int = -1):

@@ -66,7 +66,7 @@ hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* c
                    {lay.movy.data(), lay.movy.size() * 8, 0}, {lay.segs.data(), lay.segs.size() * 8, 0},
                    {c.data(), c.size() * 8, 0},               {lay.hot32.data(), lay.hot32.size() * 4, 0},
                    {lay.coop_trips.data(), lay.coop_trips.size() * 8, 0},
-                   {lay.xsegs.data(), lay.xsegs.size() * 8, 0}, {lay.xrec.data(), lay.xrec.size() * 8, 0},
+                   {lay.xhdr.data(), lay.xhdr.size() * 8, 0}, {lay.xrec.data(), lay.xrec.size() * 8, 0},
                     {lay.xpl.data(), lay.xpl.size() * 8, 0}};
   size_t total = 0;
   for (Part& p : parts) {
@@ -86,7 +86,7 @@ hipError_t DeviceLayout::put(const HostLayout& lay, const std::vector<double>* c
   cold = (const double*)(b + parts[4].off);
   hot32 = (const float*)(b + parts[5].off);
   coop_trips = (const double*)(b + parts[6].off);
-  xsegs = (const double*)(b + parts[7].off);
+  xhdr = (const double*)(b + parts[7].off);
   xrec = (const double*)(b + parts[8].off);
   xpl = (const double*)(b + parts[9].off);
   n_segs = lay.n_segs;
@@ -358,8 +358,7 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = tor::knob("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
   if (const char* c = tor::knob("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
   if (const char* c = tor::knob("TOR_SCREEN")) ctx->screen = std::atoi(c) != 0;
-  if (const char* c = tor::knob("TOR_PLANE")) ctx->plane_screen = std::atoi(c) != 0;
-  if (const char* c = tor::knob("TOR_PLANE_LDS")) ctx->plane_lds = std::atoi(c) != 0;
+  if (const char* c = tor::knob("TOR_PLANE")) ctx->plane_screen = std::atoi(c);  // 0 off, 1 gated (default), 2 on every segment that carries the table
   if (const char* c = tor::knob("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
   if (const char* c = tor::knob("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
   if (const char* c = tor::knob("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
@@ -570,15 +569,19 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       q.segs = L.segs;
       q.cold = L.cold;
       q.hot32 = L.has_f32 ? L.hot32 : nullptr;
-      q.xsegs = L.xsegs;
+      q.xhdr = L.xhdr;
       q.xrec = L.xrec;
-      q.xpl = ctx->plane_screen ? L.xpl : nullptr;
-      // stage two of the plane-screened segments reads 32-byte records per lane: from LDS when the table fits beside the
-      // per-wave queues at this launch's workgroups per CU (random_scene: 15.9 KB + 18.7 KB of 53 KB), else through the vector cache
+      q.xpl = ctx->plane_screen != 0 ? L.xpl : nullptr;
+      q.plane_gate2 = ctx->plane_screen == 2 ? 0.0 : 4.0 * tor::kPlaneGate * tor::kPlaneGate;
+      // stage two of the plane-screened segments reads its records per lane: from LDS when the table fits beside the per-wave
+      // queues at this launch's workgroups per CU (random_scene: 15.9 KB + 18.7 KB of 53 KB) and inside the 64 KB a launch may
+      // ask for without an opt-in, else through the vector cache.  Only the ARITH 2 variants stage it (brute-force layouts
+      // behind the screen: tor_kernels.hip dynamic_lds), so the room is only counted there.
       q.xrec_lds_doubles = 0;
-      if (q.xpl != nullptr && ctx->plane_lds) {
+      if (q.xpl != nullptr && ctx->screen && accel == 0) {
         const size_t wgs = (size_t)std::max(1, ctx->max_blocks_per_cu[o.seeding][0]);
-        if ((size_t)L.n_xrec * 8 + (size_t)tor::integrate_fixed_lds_bytes(0, 0) <= (size_t)(160 * 1024) / wgs - 1024) q.xrec_lds_doubles = L.n_xrec;
+        const size_t need = (size_t)L.n_xrec * 8 + (size_t)tor::integrate_fixed_lds_bytes(0, 0);
+        if (need <= (size_t)(160 * 1024) / wgs - 1024 && need <= (size_t)64 * 1024) q.xrec_lds_doubles = L.n_xrec;
       }
       q.n_segs = L.n_segs;
     };
@@ -1413,7 +1416,8 @@ int tor_selftest_screen_host(int64_t n, const double* o, const double* d, const 
 // The SECOND form of the screen (tor_screen.hpp: expanded quadratic, normalised direction) on the host, same conventions as
 // tor_selftest_screen_host.  variant 0: a static sphere through the general record (kind 10), a mover along y through kind 12,
 // any other mover through the first form (as the kernel does); variant 1: static spheres through the common-height record (kind 11);
-// variant 2: statics and movers along y through the PLANE screen (stage one of kinds 11 / 12) alone.
+// variant 2: every pair through the PLANE screen (stage one) alone -- statics and movers along y by {cx, cz}, movers in general
+// position by {c0x, c0z, dcx, dcz} (xkind 13).
 int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const double* c0, const double* dc,
                               const int32_t* moving, const double* f, const double* r2, int32_t variant, int32_t* keep, int32_t* need) {
   if (n < 0 || !o || !d || !c0 || !dc || !moving || !f || !r2 || !keep || !need)
@@ -1424,15 +1428,16 @@ int tor_selftest_screen2_host(int64_t n, const double* o, const double* d, const
   for (int64_t i = 0; i < n; ++i) {
     const double* oo = o + 3 * i; const double* dd = d + 3 * i; const double* cc0 = c0 + 3 * i; const double* dcc = dc + 3 * i;
     const bool mv = moving[i] != 0;
-    if (mv && !(dcc[0] == 0.0 && dcc[2] == 0.0)) continue;
+    const bool general = mv && !(dcc[0] == 0.0 && dcc[2] == 0.0);
+    if (general && variant != 2) continue;
     const double a = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];  // spheres.nim:30
     const double reach = up(std::sqrt(cc0[0] * cc0[0] + cc0[1] * cc0[1] + cc0[2] * cc0[2]) + std::sqrt(std::fabs(r2[i])));
     const double travel = mv ? up(std::sqrt(dcc[0] * dcc[0] + dcc[1] * dcc[1] + dcc[2] * dcc[2])) : 0.0;
     const tor::ScreenRay ray = tor::screen2_ray(oo[0], oo[1], oo[2], dd[0], dd[1], dd[2], a);
     int word;
-    if (variant == 2) {  // stage one of kinds 11 / 12: the plane screen alone (R = this object's radius)
+    if (variant == 2) {  // stage one: the plane screen alone (R = this object's radius); a mover in general position through the 4-fma chain of xkind 13
       const tor::PlaneSeg ps = tor::plane_seg(ray, tor::plane_ray(ray), reach, travel, mv ? f[i] : 0.0, r2[i]);
-      word = tor::plane_word(ps, cc0[0], cc0[2]);
+      word = general ? tor::plane_word_mov(ps, cc0[0], cc0[2], dcc[0], dcc[2]) : tor::plane_word(ps, cc0[0], cc0[2]);
     } else if (mv) {
       const tor::ScreenSeg sg = tor::screen2_seg(ray, reach, travel, cc0[1], f[i]);
       word = tor::screen2_movy_y(sg, cc0[0], cc0[2], tor::screen2_Ky(cc0[0], cc0[2], r2[i]), dcc[1]);
@@ -1506,14 +1511,15 @@ int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double
   return TOR_OK;
 }
 
-// The strict brute-force layout's SECOND-FORM segments on the HOST over a whole scene: builds the layout tor_scene_upload builds
-// (no float32 segments) and walks its kinds 10 / 11 / 12 for each ray as integrate_kernel's ARITH 2 loop does -- kinds 11 / 12
-// through the plane screen first (the {cx, cz} table, the segment's largest radius^2), then the second form on the 32-byte record;
-// kind 10 through the second form alone.  keep[ray * world.len + object] = 0 dropped by the plane screen, 1 dropped by the second
-// form, 2 a candidate of the exact test, 3 the object is on a first-form segment (a general mover, a mover without a common height).
-// kind_out[object] (nullable) = its segment's kind (0 first form, 10, 11, 12).  No device needed.
+// The strict brute-force layout's SCREENED segments on the HOST over a whole scene: builds the layout tor_scene_upload builds
+// (no float32 segments) and walks its xkinds 10-14 for each ray as integrate_kernel's ARITH 2 loop does when stage one runs --
+// the plane screen first (the segment's plane table, its largest radius^2), then the segment's own test on the per-lane record:
+// the second form for 10 / 11 / 12 (32 bytes), the first form for 13 / 14 (64 bytes).  keep[ray * world.len + object] = 0 dropped
+// by the plane screen, 1 dropped by stage two, 2 a candidate of the exact test, 3 the object is on a segment without a table (a
+// time group whose fraction is never finite).  kind_out[object] (nullable) = its segment's xkind (0, 10-14);
+// pays_out[ray * n_segs_out + segment] (nullable, with n_segs_out) = plane_pays' vote of that ray.  No device needed.
 int tor_debug_screen2_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d, const double* time, int8_t* keep,
-                            int32_t* kind_out) {
+                            int32_t* kind_out, int8_t* pays_out, int64_t n_segs_out) {
   if (world.len < 0 || (world.len > 0 && !world.objects) || n_rays < 0 || !o || !d || !time || !keep)
     return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_screen2_scene: bad argument");
   std::vector<int64_t> ids((size_t)world.len);
@@ -1541,22 +1547,35 @@ int tor_debug_screen2_scene(TorHittableList world, int64_t n_rays, const double*
       if (r == 0 && kind_out)
         for (int i = 0; i < real; ++i) kind_out[orig_of((size_t)block0 * tor::kPad + (size_t)i)] = xkind;
       if (xkind < 10) continue;
-      const double f = xkind == 12 ? (time[r] - sg[4]) / sg[5] : 0.0;  // moving_spheres.nim:42
+      const double f = xkind >= 12 ? (time[r] - sg[4]) / sg[5] : 0.0;  // moving_spheres.nim:42
       const tor::ScreenSeg ss = tor::screen2_seg(ray, sg[6], sg[7], xs[2], f);
       const tor::PlaneSeg ps = tor::plane_seg(ray, pray, sg[6], sg[7], f, xs[4]);
+      double negmu = 0.0, am = 0.0;  // first form (13 / 14): integrate_loop_plane.inc / integrate_loop_f64_movers.inc
+      tor::screen_margins(ray.s1 + sg[6] + sg[7] * std::fabs(f), std::fabs(dd[0]) + std::fabs(dd[1]) + std::fabs(dd[2]), a, negmu, am);
+      const size_t xsz = xkind >= 13 ? 8 : 4, pw = xkind == 13 ? 4 : 2;
       for (int i = 0; i < real; ++i) {
-        const double* x = &lay.xrec[(size_t)xs[1] + 4 * (size_t)i];
+        const double* x = &lay.xrec[(size_t)xs[1] + xsz * (size_t)i];
+        const double* pl = &lay.xpl[(size_t)xs[3] + pw * (size_t)i];
+        const bool table_ok = xkind == 10   ? (pl[0] == x[0] && pl[1] == x[2])
+                              : xkind <= 12 ? (pl[0] == x[0] && pl[1] == x[1])
+                              : xkind == 13 ? (pl[0] == x[0] && pl[1] == x[2] && pl[2] == x[4] && pl[3] == x[6])
+                                            : (pl[0] == x[0] && pl[1] == x[2] && x[4] == 0.0 && x[6] == 0.0);
+        if (!table_ok) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_screen2_scene: the plane table and the records disagree (layout bug)");
         int8_t verdict;
-        if (xkind == 10) {
-          verdict = tor::screen2_static(ss, x[0], x[1], x[2], x[3]) < 0 ? 2 : 1;
+        const int w1 = xkind == 13 ? tor::plane_word_mov(ps, pl[0], pl[1], pl[2], pl[3]) : tor::plane_word(ps, pl[0], pl[1]);
+        if (w1 >= 0) {
+          verdict = 0;
         } else {
-          const double* pl = &lay.xpl[(size_t)xs[3] + 2 * (size_t)i];
-          if (!(pl[0] == x[0] && pl[1] == x[1])) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_screen2_scene: the plane table and the records disagree (layout bug)");
-          if (tor::plane_word(ps, pl[0], pl[1]) >= 0) verdict = 0;
-          else verdict = (xkind == 12 ? tor::screen2_movy_y(ss, x[0], x[1], x[2], x[3]) : tor::screen2_static_y(ss, x[0], x[1], x[2])) < 0 ? 2 : 1;
+          int w2;
+          if (xkind == 10) w2 = tor::screen2_static(ss, x[0], x[1], x[2], x[3]);
+          else if (xkind == 11) w2 = tor::screen2_static_y(ss, x[0], x[1], x[2]);
+          else if (xkind == 12) w2 = tor::screen2_movy_y(ss, x[0], x[1], x[2], x[3]);
+          else w2 = tor::screen_filter(tor::fma_(-f, x[4], oo[0] - x[0]), tor::fma_(-f, x[5], oo[1] - x[1]), tor::fma_(-f, x[6], oo[2] - x[2]), dd[0], dd[1], dd[2], a, negmu, am, x[3]);
+          verdict = w2 < 0 ? 2 : 1;
         }
         kr[orig_of((size_t)block0 * tor::kPad + (size_t)i)] = verdict;
       }
+      if (pays_out && s < n_segs_out) pays_out[r * n_segs_out + s] = tor::plane_pays(pray, 4.0 * tor::kPlaneGate * tor::kPlaneGate, xs[4], xs[5], xs[6]) ? 1 : 0;
     }
   }
   return TOR_OK;

@@ -72,7 +72,7 @@ struct DeviceLayout {
   const double *stat = nullptr, *mov = nullptr, *movy = nullptr, *segs = nullptr, *cold = nullptr;
   const float* hot32 = nullptr;
   const double* coop_trips = nullptr;  // coop_pixel_kernel: 4 float64 per trip of 64 cold slots
-  const double *xsegs = nullptr, *xrec = nullptr, *xpl = nullptr;  // second form of the FMA screen and its stage one (tor_scene.hpp)
+  const double *xhdr = nullptr, *xrec = nullptr, *xpl = nullptr;  // second form of the FMA screen and its stage one (tor_scene.hpp)
   int n_segs = 0;
   int n_sorted = 0;  // cold slots (padded)
   int n_xrec = 0;    // float64 in xrec
@@ -139,8 +139,7 @@ struct TorContext {
   std::vector<double> probe_bnd_host[kRing];  // block bounds of the cost probe when it runs with other accel bits than the frame (host staging of an
   std::vector<float> probe_bnd32_host[kRing];  // asynchronous copy, per ring slot like bnd_host)
   bool probe_accel = true;  // TOR_PROBE_ACCEL=0: the probe walks the same layout as the frame's kernel
-  bool plane_lds = true;      // TOR_PLANE_LDS=0: stage two of the plane-screened segments reads its records through the vector cache, never from LDS
-  bool plane_screen = true;  // TOR_PLANE=0: the screen's second form tests every object (no plane screen in front of kinds 11 / 12)
+  int plane_screen = 1;  // TOR_PLANE: 0 = the wave-uniform test for every object (no plane screen in front), 1 = stage one where it pays (tor_screen.hpp plane_pays), 2 = on every segment with a table
   bool screen = true;       // TOR_SCREEN=0: strict brute-force launches evaluate the reference's unfused discriminant for every object (no FMA screen)
   hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
   int64_t launches = 0;  // timed integrator launches so far

@@ -510,19 +510,63 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           }                                                                    \
         }
         while (seg < p.n_segs) {
-          const int seg_kind = (int)segs[seg * 8 + 0];
-          const int seg_begin = (int)segs[seg * 8 + 1];    // first hot record of the segment
-          const int seg_count_word = (int)segs[seg * 8 + 2];
+          // ---- the segment's header.  ARITH 2 (round 5): ONE 128-byte record per segment (KParams.xhdr, tor_scene.hpp) read up front
+          // -- two s_load_dwordx16 issued together, one round trip through the scalar cache -- with the integers stored as integers.
+          // Before, a plane-screened segment paid three DEPENDENT round trips (kind -> offsets, margins, gate inputs -> first record)
+          // and a v_cvt_i32_f64 + v_readfirstlane per integer field; under the scalar traffic of twelve waves per CU walking
+          // the plane table a dependent round trip is ~0.3 us of a 30 us bounce iteration (measured: one more of them per query,
+          // for the gate of a 4-object segment, cost 2 %).  The header also carries the segment's FIRST plane record, so the loop's
+          // first request (record 1 on) overlaps the per-segment set-up instead of following it.
+          int seg_kind, seg_begin, seg_count_word, seg_block0, xkind = 0, h_xfirst = 0, h_plfirst = 0, h_gate = 0;
+          double h_t0 = 0.0, h_dt = 1.0, h_reach = 0.0, h_travel = 0.0, h_y = 0.0, h_rmax2 = 0.0, h_sx = 0.0, h_sz = 0.0;
+          double h_r0 = 0.0, h_r1 = 0.0, h_r2 = 0.0, h_r3 = 0.0;
+          if constexpr (kScreen) {
+            // (written as two s_load_dwordx16 by hand: left to itself the compiler sinks every field's load to its first use -- a
+            // load per branch again -- and then carries some of the integers in vector registers, which turns the object loop's
+            // record addresses, and with them its scalar loads, into per-lane vector loads: measured, 1.6 x slower)
+            typedef int __attribute__((ext_vector_type(16))) i16v;
+            const double* hp = p.xhdr + (size_t)seg * 16;
+            i16v ha, hb;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ha), "=&s"(hb) : "s"(hp) : "memory");
+            auto f64_of = [](int lo, int hi_) { return __hiloint2double(hi_, lo); };
+            xkind = ha[0]; seg_kind = ha[1]; seg_count_word = ha[2]; seg_block0 = ha[3]; seg_begin = ha[4]; h_xfirst = ha[5]; h_plfirst = ha[6]; h_gate = ha[7];
+            h_t0 = f64_of(ha[8], ha[9]); h_dt = f64_of(ha[10], ha[11]); h_reach = f64_of(ha[12], ha[13]); h_travel = f64_of(ha[14], ha[15]);
+            h_y = f64_of(hb[0], hb[1]); h_rmax2 = f64_of(hb[2], hb[3]); h_sx = f64_of(hb[4], hb[5]); h_sz = f64_of(hb[6], hb[7]);
+            h_r0 = f64_of(hb[8], hb[9]); h_r1 = f64_of(hb[10], hb[11]); h_r2 = f64_of(hb[12], hb[13]); h_r3 = f64_of(hb[14], hb[15]);
+          } else {
+            seg_kind = (int)segs[seg * 8 + 0];
+            seg_begin = (int)segs[seg * 8 + 1];    // first hot record of the segment
+            seg_count_word = (int)segs[seg * 8 + 2];
+            seg_block0 = (int)segs[seg * 8 + 3];   // (first sorted index) / kBlock
+          }
           const int seg_count = seg_count_word & 0xffffff;   // padded to kBlock
           const int seg_real = seg_count - (seg_count_word >> 24);  // kinds 0-2: the objects that exist (the last block's tail is padding)
-          const int seg_block0 = (int)segs[seg * 8 + 3];   // (first sorted index) / kBlock
-          // ARITH 2: segments with second-form records (tor_screen.hpp: the quadratic expanded around the ray, direction
-          // normalised per ray -- 8 / 6 / 9 float64 instructions per object, all but one fused multiply-adds against scalar
-          // operands); the others keep the first form below
-          const int xkind = kScreen ? (int)as_const(p.xsegs)[seg * 8 + 0] : 0;
-          if (kScreen && xkind >= 11 && p.xpl != nullptr) {
+          // (what the segment loops read of the header: from the record above in the ARITH 2 variants, from segs[] in the others --
+          // kScreen is a compile-time constant, the dead arm emits nothing)
+#define SEG_T0 (kScreen ? h_t0 : segs[seg * 8 + 4])
+#define SEG_DT (kScreen ? h_dt : segs[seg * 8 + 5])
+#define SEG_REACH (kScreen ? h_reach : segs[seg * 8 + 6])
+#define SEG_TRAVEL (kScreen ? h_travel : segs[seg * 8 + 7])
+          // ARITH 2: segments with second-form records (xkind 10 / 11 / 12; tor_screen.hpp: the quadratic expanded around the ray,
+          // direction normalised per ray -- 8 / 6 / 9 float64 instructions per object, all but one fused multiply-adds against scalar
+          // operands); the others (13 / 14: movers in general position; 0: degenerate time groups) keep the first form below
+          // stage one (the plane screen, kernel/integrate_loop_plane.inc) in front of the segment's wave-uniform test: when the
+          // launch carries the table and the band around the ground track is thin against the segment for most of the wave's rays
+          // (tor_screen.hpp plane_pays; the same vote on every pass of a query: the rays do not change)
+          // (the host settles the clear cases per segment -- h_gate 1: the band is thin whatever the track's direction, 0: never
+          // (a segment of a few huge spheres), 2: it depends on the direction: the wave votes; random_scene has no segment of the
+          // third kind.  A vote costs ~35 vector instructions with the scalar-register spills around it.)
+          bool use_plane = false;
+          if (kScreen && xkind >= 10 && p.xpl != nullptr) {
+            use_plane = h_gate == 1 || p.plane_gate2 <= 0.0;
+            if (h_gate == 2 && p.plane_gate2 > 0.0) {
+              const bool pays = plane_pays(pray, p.plane_gate2, h_rmax2, h_sx, h_sz);
+              use_plane = 2 * __builtin_popcountll(ballot64(pays)) > __builtin_popcountll(active_mask);
+            }
+          }
+          if (kScreen && use_plane) {
 #include "kernel/integrate_loop_plane.inc"
-          } else if (kScreen && xkind >= 10) {
+          } else if (kScreen && xkind >= 10 && xkind <= 12) {
 #include "kernel/integrate_loop_screen2.inc"
           } else if (seg_kind == 0) {
 #include "kernel/integrate_loop_f64_static.inc"
@@ -539,6 +583,10 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
           seg += 1;
           i = 0;
         }
+#undef SEG_T0
+#undef SEG_DT
+#undef SEG_REACH
+#undef SEG_TRAVEL
 #undef TOR_WORDS_END_BLOCK
         if (kWords) {
           if (!full && (gb_next & 3) != 0) {  // the list ended inside a word: its bits move up into place

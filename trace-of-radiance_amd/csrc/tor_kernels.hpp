@@ -39,10 +39,11 @@ struct KParams {
   const double* movy;
   const double* segs;
   const double* cold;
-  const double* xsegs;  // per segment {xkind, first float64 of its records in xrec, common c0.y}: second form of the FMA screen (tor_screen.hpp, tor_scene.hpp)
   const double* xrec;
   int xrec_lds_doubles; // > 0: stage two reads the second-form records from LDS (that many float64 of xrec copied per workgroup); 0: vector loads
-  const double* xpl;    // stage one of kinds 11 / 12 (the plane screen): {cx, cz} per slot; null = second form for every object (TOR_PLANE=0)
+  const double* xhdr;   // ARITH 2: one 128-byte header per segment (16 float64 slots; tor_scene.hpp HostLayout::xhdr), everything the object loop reads per segment
+  const double* xpl;    // stage one of every xkind >= 10 (the plane screen): {cx, cz} per slot ({c0x, c0z, dcx, dcz} for xkind 13); null = the wave-uniform test for every object (TOR_PLANE=0)
+  double plane_gate2;   // stage one runs on a segment when most of the wave's rays expect it to keep less than 1 / gate of the segment (tor_screen.hpp plane_pays; 4 gate^2); 0 = always (TOR_PLANE=2)
   const float* hot32;  // TOR_ACCEL_F32 pair records, or null
   double org[3];       // origin of the float32 coordinates
   const double* bnd;   // TOR_ACCEL_BLOCKS: 8 float64 per block {lo xyz, hi xyz, 0, 0} (segment kind 3), else null

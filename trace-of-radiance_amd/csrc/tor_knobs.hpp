@@ -39,8 +39,7 @@ constexpr Knob kKnobs[] = {
     {"TOR_WAVES_PER_SIMD", "(from the launch shape)", "2 | 3", "context", "force the register-budget variant of integrate_kernel (256 / 168 VGPRs)"},
     {"TOR_STAGE_LDS", "(no cap)", "bytes, 0 = off", "call", "cap of the LDS staging of block records / boxes (TOR_ACCEL_BLOCKS)"},
     {"TOR_SCREEN", "1", "0 | 1", "context", "0: strict brute-force launches evaluate the reference's unfused discriminant for every object instead of the conservative FMA screen (same canvas)"},
-    {"TOR_PLANE", "1", "0 | 1", "context", "0: the FMA screen runs its second form on every object of a common-height segment instead of the 4-instruction plane screen first and the second form on what that keeps (same candidates, same canvas)"},
-    {"TOR_PLANE_LDS", "1", "0 | 1", "context", "0: stage two behind the plane screen reads the second-form records through the vector cache even when the table fits in LDS"},
+    {"TOR_PLANE", "1", "0 | 1 | 2", "context", "stage one of the FMA screen (the 4-instruction plane screen in front of the segment's wave-uniform test, per-lane stage two on what it keeps): 0 off, 1 on the segments where it pays (default), 2 on every segment (same candidates, same canvas)"},
     {"TOR_TWO_LEVEL_MIN", "96", "blocks", "upload", "culling layouts with MORE than this many boxes get super boxes (two-level)"},
     // ---- TOR_SEED_PIXEL: kernel choice, cost probe, tile schedule ----
     {"TOR_COOP_MAX_PIXELS", "114688", ">= 0", "context", "frames up to this many pixels (per device) run one WAVE per pixel when neither hand-off nor split mode applies; 0 = never"},

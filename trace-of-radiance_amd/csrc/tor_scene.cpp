@@ -167,10 +167,29 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   // it bit for bit (spheres resting on a plane) form segments of their own when there are at least kPad of them -- the second
   // form of the strict loop's FMA screen hoists their y terms out of the per-object work (tor_screen.hpp: kinds 11, 12).  The
   // order of the objects is free (closest hit is order independent, ties go by the original index in the cold record).
+  // Round 5: every segment of finite parameters carries a plane table (stage one of the screen, tor_screen.hpp), whose band is as
+  // wide as the segment's LARGEST sphere -- so spheres much larger than the segment's typical member (r^2 > 16 x the median: the
+  // ground and the three big spheres of random_scene) are set apart first.
   struct Seg64 { int kind; std::vector<int64_t> ids; double t0, dt; int xkind; double y; };
   std::vector<Seg64> segs64;
   auto y_of = [&](int64_t i) { return objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.center.y : objs[i].u.moving_sphere.center0.y; };
-  auto cut_by_y = [&](const std::vector<int64_t>& members, int kind, double t0, double dt, int xkind_rest, int xkind_uniform) {
+  auto r2_of = [&](int64_t i) {
+    const double r = objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.radius : objs[i].u.moving_sphere.radius;
+    return r * r;
+  };
+  auto cut_by_y = [&](const std::vector<int64_t>& all_members, int kind, double t0, double dt, int xkind_rest, int xkind_uniform) {
+    std::vector<int64_t> members, big;
+    if (all_members.size() >= 2 * (size_t)kPad) {
+      std::vector<double> r2s;
+      for (int64_t i : all_members) r2s.push_back(r2_of(i));
+      std::nth_element(r2s.begin(), r2s.begin() + r2s.size() / 2, r2s.end());
+      const double limit = 16.0 * r2s[r2s.size() / 2];
+      for (int64_t i : all_members) (r2_of(i) > limit ? big : members).push_back(i);   // (a NaN radius stays with the members: fmax skips it below)
+    } else {
+      members = all_members;
+    }
+    if (!big.empty()) segs64.push_back({kind, big, t0, dt, xkind_rest, 0.0});
+    if (members.empty()) return;
     std::vector<std::pair<uint64_t, std::vector<int64_t>>> by_y;  // in order of first appearance
     for (int64_t i : members) {
       const double y = y_of(i);
@@ -206,17 +225,30 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   if (!statics.empty()) cut_by_y(statics, 0, 0.0, 1.0, 10, 11);
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const TorMovingSphere& first = objs[groups[gi].ids[0]].u.moving_sphere;
-    const bool y = group_moves_along_y_only(objs, groups[gi]);
     const double t0 = first.time0, dt = first.time1 - first.time0;
-    // (kinds 1 / 2 without a second-form record keep the first form of the screen: xkind 0)
-    cut_by_y(groups[gi].ids, y ? 1 : 2, t0, dt, 0, (y && std::isfinite(t0) && std::isfinite(dt) && dt != 0.0) ? 12 : 0);
+    // xkind of a segment of movers: 12 along y with a common c0.y (second form), 14 along y at any height, 13 in general position
+    // (13 / 14: stage one in front of the FIRST form); a group whose time fraction can never be finite keeps the first form
+    // alone (xkind 0): the reference cannot hit such a centre, no stage is worth building for it.  A time group is cut into its
+    // members that move along y only (c1.x == c0.x and c1.z == c0.z: c0 + f * 0 == c0 exactly) and the others (round 5: one
+    // mover in general position no longer takes the whole group's y-only members off the cheaper records).
+    const bool sane = std::isfinite(t0) && std::isfinite(dt) && dt != 0.0;
+    TimeGroup gy{groups[gi].k0, groups[gi].k1, {}}, gg{groups[gi].k0, groups[gi].k1, {}};
+    for (int64_t idx : groups[gi].ids) {
+      const TorMovingSphere& s = objs[idx].u.moving_sphere;
+      ((s.center1.x - s.center0.x == 0.0 && s.center1.z - s.center0.z == 0.0) ? gy : gg).ids.push_back(idx);
+    }
+    if (!gy.ids.empty()) cut_by_y(gy.ids, 1, t0, dt, sane ? 14 : 0, sane ? 12 : 0);
+    if (!gg.ids.empty()) cut_by_y(gg.ids, 2, t0, dt, sane ? 13 : 0, 0);
   }
+  // float64 per slot of the second-stage records (xrec) and of the plane table (xpl), by xkind
+  auto xs_of = [](int xkind) { return xkind == 0 ? 0 : (xkind >= 13 ? 8 : 4); };
+  auto pw_of = [](int xkind) { return xkind == 0 ? 0 : (xkind == 13 ? 4 : 2); };
   size_t n_stat_p = 0, n_mov_p = 0, n_movy_p = 0, n_xrec = 0, n_xpl = 0;
   for (const Seg64& sg : segs64) {
     const size_t cp = padded(sg.ids.size());
     (sg.kind == 0 ? n_stat_p : (sg.kind == 1 ? n_movy_p : n_mov_p)) += cp;
-    n_xrec += cp * (sg.xkind != 0 ? 4 : 0);
-    n_xpl += cp * (sg.xkind >= 11 ? 2 : 0);
+    n_xrec += cp * (size_t)xs_of(sg.xkind);
+    n_xpl += cp * (size_t)pw_of(sg.xkind);
   }
   std::vector<char> yonly32(groups32.size(), 0);
   size_t n32_slots = padded(statics32.size()), n32_floats = padded(statics32.size()) / 2 * 10;
@@ -252,30 +284,46 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   for (const Seg64& sg : segs64) {
     const size_t cnt_p = padded(sg.ids.size());
     double reach = 0.0, travel = 0.0, rmax2 = 0.0;
+    // bounding box of the centres' ground projection (+ the movers' travel): what plane_pays (tor_screen.hpp) weighs the band against
+    double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY, dcx_max = 0.0, dcz_max = 0.0;
+    auto grow = [&](double x, double z) {
+      if (std::isfinite(x)) { xlo = std::fmin(xlo, x); xhi = std::fmax(xhi, x); }
+      if (std::isfinite(z)) { zlo = std::fmin(zlo, z); zhi = std::fmax(zhi, z); }
+    };
     for (int64_t idx : sg.ids) {
       if (sg.kind == 0) {
         const TorSphere& s = objs[idx].u.sphere;
         reach = std::fmax(reach, norm3(s.center.x, s.center.y, s.center.z) + std::fabs(s.radius));
         rmax2 = std::fmax(rmax2, s.radius * s.radius);
+        grow(s.center.x, s.center.z);
       } else {
         const TorMovingSphere& s = objs[idx].u.moving_sphere;
         reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
         rmax2 = std::fmax(rmax2, s.radius * s.radius);
         travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
+        grow(s.center0.x, s.center0.z);
+        dcx_max = std::fmax(dcx_max, std::fabs(s.center1.x - s.center0.x));
+        dcz_max = std::fmax(dcz_max, std::fabs(s.center1.z - s.center0.z));
       }
     }
+    const double ext_x = xhi >= xlo ? (xhi - xlo) + dcx_max : 0.0, ext_z = zhi >= zlo ? (zhi - zlo) + dcz_max : 0.0;
     const size_t first_rec = sg.kind == 0 ? stat_rec : (sg.kind == 1 ? movy_rec : mov_rec);
     // (segs[2] of kinds 0-2: padded count | padding records << 24 -- the kernel tests only the real objects of the last block)
     out.segs.insert(out.segs.end(), {(double)sg.kind, (double)first_rec, (double)(cnt_p | ((cnt_p - sg.ids.size()) << 24)), (double)(sorted / kPad),
                                      sg.kind == 0 ? 0.0 : sg.t0, sg.kind == 0 ? 0.0 : sg.dt, up(reach), up(travel)});
-    // second-form records of the screen (tor_screen.hpp): {xkind, first float64 of the records, common c0.y}
-    // ... and of its stage one (kinds 11 / 12): first float64 of the segment's {cx, cz} pairs in xpl, largest radius^2 (a NaN
-    // radius: fmax skipped it -- and the reference can never hit that sphere)
-    out.xsegs.insert(out.xsegs.end(), {(double)sg.xkind, (double)x_off, sg.y, (double)pl_off, rmax2, 0.0, 0.0, 0.0});
-    const size_t xs = sg.xkind != 0 ? 4 : 0;
-    for (size_t k = 0; k < cnt_p && xs != 0; ++k) {  // padding: never a candidate (t'' = T - 1e300 < 0, disc'' < 0), except for a wild ray, which the exact test rejects
+    // per-lane stage-two records of the screen (tor_screen.hpp): {xkind, first float64 of the records, common c0.y}
+    // ... and of its stage one: first float64 of the segment's plane table in xpl, largest radius^2 (a NaN radius: fmax skipped
+    // it -- and the reference can never hit that sphere), extents of the centres' ground projection
+    out.xsegs.insert(out.xsegs.end(), {(double)sg.xkind, (double)x_off, sg.y, (double)pl_off, rmax2, ext_x, ext_z, 0.0});
+    const size_t xs = (size_t)xs_of(sg.xkind), pw = (size_t)pw_of(sg.xkind);
+    for (size_t k = 0; k < cnt_p && xs != 0; ++k) {  // padding: never a candidate (second form: t'' = T - 1e300 < 0, disc'' < 0; first form: r^2 = -1), except for a wild ray, which the exact test rejects
       double* x = &out.xrec[x_off + xs * k];
-      x[sg.xkind == 10 ? 3 : 2] = 1e300;
+      if (xs == 4) x[sg.xkind == 10 ? 3 : 2] = 1e300;
+      else x[3] = -1.0;
+    }
+    for (size_t k = 0; k < cnt_p && pw == 4; ++k) {  // (the table's fill value 1e300 is a centre far from every ground track; a mover's dc slots must not carry it)
+      double* pl = &out.xpl[pl_off + 4 * k];
+      pl[2] = 0.0; pl[3] = 0.0;
     }
     for (size_t k = 0; k < sg.ids.size(); ++k) {
       const TorHittableVariant& hv = objs[sg.ids[k]];
@@ -286,10 +334,8 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
         m[3] = s.radius * s.radius;
         double* x = &out.xrec[x_off + 4 * k];
         if (sg.xkind == 10) { x[0] = s.center.x; x[1] = s.center.y; x[2] = s.center.z; x[3] = screen2_K(s.center.x, s.center.y, s.center.z, s.radius * s.radius); }
-        else {
-          x[0] = s.center.x; x[1] = s.center.z; x[2] = screen2_Ky(s.center.x, s.center.z, s.radius * s.radius); x[3] = 0.0;
-          out.xpl[pl_off + 2 * k] = s.center.x; out.xpl[pl_off + 2 * k + 1] = s.center.z;
-        }
+        else { x[0] = s.center.x; x[1] = s.center.z; x[2] = screen2_Ky(s.center.x, s.center.z, s.radius * s.radius); x[3] = 0.0; }
+        out.xpl[pl_off + 2 * k] = s.center.x; out.xpl[pl_off + 2 * k + 1] = s.center.z;
       } else {
         const TorMovingSphere& s = hv.u.moving_sphere;
         const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
@@ -302,20 +348,29 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
             double* x = &out.xrec[x_off + 4 * k];
             x[0] = s.center0.x; x[1] = s.center0.z; x[2] = screen2_Ky(s.center0.x, s.center0.z, s.radius * s.radius);
             x[3] = dcy;
-            out.xpl[pl_off + 2 * k] = s.center0.x; out.xpl[pl_off + 2 * k + 1] = s.center0.z;
           }
+          if (sg.xkind != 0) { out.xpl[pl_off + 2 * k] = s.center0.x; out.xpl[pl_off + 2 * k + 1] = s.center0.z; }
         } else {
           double* m = &out.mov[8 * (mov_rec + k)];
           m[0] = s.center0.x; m[1] = s.center0.y; m[2] = s.center0.z;
           m[3] = s.radius * s.radius;
           m[4] = dcx; m[5] = dcy; m[6] = dcz;
+          if (sg.xkind == 13) {
+            double* pl = &out.xpl[pl_off + 4 * k];
+            pl[0] = s.center0.x; pl[1] = s.center0.z; pl[2] = dcx; pl[3] = dcz;
+          }
+        }
+        if (sg.xkind >= 13) {  // stage two of 13 / 14 runs the first form per lane: the mover record, 64 bytes for either kind
+          double* x = &out.xrec[x_off + 8 * k];
+          x[0] = s.center0.x; x[1] = s.center0.y; x[2] = s.center0.z; x[3] = s.radius * s.radius;
+          x[4] = dcx; x[5] = dcy; x[6] = dcz; x[7] = 0.0;
         }
       }
       if (!fill_cold(&out.cold[16 * (sorted + k)], hv, sg.ids[k])) { err = "unknown Material kind"; return false; }
     }
     (sg.kind == 0 ? stat_rec : (sg.kind == 1 ? movy_rec : mov_rec)) += cnt_p;
     x_off += cnt_p * xs;
-    pl_off += cnt_p * (sg.xkind >= 11 ? 2 : 0);
+    pl_off += cnt_p * pw;
     sorted += cnt_p;
   }
 
@@ -369,6 +424,33 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   out.n_segs = (int)(out.segs.size() / 8);
   if (out.segs.empty()) out.segs.assign(8, 0.0);
   if (out.xsegs.empty()) out.xsegs.assign(8, 0.0);
+  // ---- xhdr: what the ARITH 2 object loop reads per segment, as ONE 128-byte record (tor_scene.hpp): the integer fields of segs /
+  // xsegs as 32-bit integers (the loop's scalar unit has no float64 -> int conversion), the float64 fields, the first plane record
+  out.xhdr.assign(16 * (size_t)std::max(out.n_segs, 1) + 16, 0.0);
+  for (int s = 0; s < out.n_segs; ++s) {
+    const double* sg = &out.segs[8 * (size_t)s];
+    const double* xs = &out.xsegs[8 * (size_t)s];
+    double* h = &out.xhdr[16 * (size_t)s];
+    // the plane screen's gate, settled here where it does not depend on the ray (tor_screen.hpp plane_pays: the band 2 R against the
+    // width E of the centres' box across the ground track, E between min(Sx, Sz) and hypot(Sx, Sz)): 1 always, 0 never, 2 the wave votes
+    // ... and never on a segment of fewer than 48 objects: two stages' set-up costs more than 3 instructions per object save
+    int32_t gate = 0;
+    const int n_real = ((int)sg[2] & 0xffffff) - ((int)sg[2] >> 24);
+    if ((int)xs[0] >= 10 && n_real >= 48) {
+      const double band = 2.0 * kPlaneGate * std::sqrt(xs[4]);
+      const double e_min = std::fmin(xs[5], xs[6]), e_max = std::hypot(xs[5], xs[6]);
+      gate = band < e_min ? 1 : (band < e_max ? 2 : 0);     // (a NaN anywhere: never)
+    }
+    const int32_t ints[8] = {(int32_t)xs[0], (int32_t)sg[0], (int32_t)sg[2], (int32_t)sg[3], (int32_t)sg[1], (int32_t)xs[1], (int32_t)xs[3], gate};
+    std::memcpy(h, ints, sizeof(ints));
+    h[4] = sg[4]; h[5] = sg[5]; h[6] = sg[6]; h[7] = sg[7];
+    h[8] = xs[2]; h[9] = xs[4]; h[10] = xs[5]; h[11] = xs[6];
+    const int xkind = (int)xs[0];
+    if (xkind >= 10) {
+      const size_t pw = xkind == 13 ? 4 : 2;
+      for (size_t k = 0; k < pw; ++k) h[12 + k] = out.xpl[(size_t)xs[3] + k];
+    }
+  }
   // trip table of the one-wave-per-pixel kernel
   const size_t n_trips = (out.n_sorted + 63) / 64;
   out.coop_trips.assign(4 * n_trips + 4, 0.0);

@@ -18,6 +18,10 @@ struct HostLayout {
   // common c0.y, 12 mover along y with a common c0.y), first float64 of its records in xrec, the common c0.y, 0...}; records
   // {cx, cy, cz, K} | {cx, cz, K', 0} | {cx, cz, K', dcy}: 4 float64 each, padded like the first form's
   std::vector<double> xsegs, xrec;
+  // what the kernel reads of segs / xsegs, one 128-byte record per segment (16 float64 slots): int32 {xkind, kind, padded count |
+  // padding << 24, first block, first hot record, first float64 in xrec, first float64 in xpl, the plane screen's gate (0 never, 1 always, 2 the wave votes)}, then float64 {time0, time1 -
+  // time0, reach, travel, common c0.y, largest radius^2, extent x, extent z} and the segment's first plane record (4 slots)
+  std::vector<double> xhdr;
   // stage one in front of it (tor_screen.hpp: the plane screen, kinds 11 / 12 only): {cx, cz} per slot -- 16 bytes, the wave-uniform
   // loop reads nothing else -- at xpl[xsegs[3] + 2 * slot of the segment]; xsegs[4] = the largest radius^2 of the segment
   std::vector<double> xpl;

@@ -173,13 +173,14 @@ TOR_HD int screen2_word(double nh, double tn) {
   return (int)(unsigned)(double_to_bits(q) >> 32);
 }
 // kind 10: record {cx, cy, cz, K = |c|^2 - r^2}
+// (kLane: the record is the lane's own -- vector registers -- instead of wave-uniform)
+template <bool kLane = false>
 TOR_HD int screen2_static(const ScreenSeg& s, double cx, double cy, double cz, double K) {
-  const double nh = fma_clamp_s(cx, s.hx, fma_(cy, s.hy, fma_(cz, s.hz, s.Pn)));
+  const double nh = kLane ? fma_clamp_v(cx, s.hx, fma_(cy, s.hy, fma_(cz, s.hz, s.Pn))) : fma_clamp_s(cx, s.hx, fma_(cy, s.hy, fma_(cz, s.hz, s.Pn)));
   const double tn = fma_(s.ks, K, fma_(s.a2x, cx, fma_(s.a2y, cy, fma_(s.a2z, cz, s.Tn))));
   return screen2_word(nh, tn);
 }
 // kind 11: record {cx, cz, K' = cx^2 + cz^2 - r^2}
-// (kLane: the record is the lane's own -- vector registers -- instead of wave-uniform)
 template <bool kLane = false>
 TOR_HD int screen2_static_y(const ScreenSeg& s, double cx, double cz, double K) {
   const double nh = kLane ? fma_clamp_v(cx, s.hx, fma_(cz, s.hz, s.Pn)) : fma_clamp_s(cx, s.hx, fma_(cz, s.hz, s.Pn));
@@ -223,6 +224,19 @@ TOR_HD double screen2_Ky(double cx, double cz, double r2) { return (cx * cx + cz
 // c_xz is exact here: statics, and movers whose c1 - c0 has x = z = 0 exactly (group_moves_along_y_only).
 // A ray whose ground track has no direction (w2 < 2^-200: vertical), whose threshold leaves the normal range, or that is wild
 // keeps everything.
+//
+// Round 5 -- the test never reads y, so it serves EVERY float64 segment, not only the common-height ones it was built for:
+//   xkind 10 (statics at any height) and 14 (movers along y at any height): the same {cx, cz} table, the same 4 instructions;
+//   xkind 13 (movers whose centre travels in x or z): c^_xz = c0_xz + f dc_xz is evaluated inside the chain,
+//       s' = nx c0x + nz c0z + (f nx) dcx + (f nz) dcz + c0       record {c0x, c0z, dcx, dcz}: 5 float64 instructions + the v_alignbit
+//     against the exact c^ = c0 + f dc that the first form's analysis of the reference is stated for (the reference's own centre,
+//     c0 + dc*f rounded twice, is within 3.1 u B of it per component, which the 48 u B^2 above already contains).  Two more
+//     roundings in the chain and one each in f nx, f nz (|f nx dcx| <= w |f| |dc| <= w B):  |s' - n~ . (c^_xz - o_xz)| <=
+//     (3.1 + 6 x 2.83 + 2) u w B < 22.1 u w B, so s'^2 < w^2 (r^2 + (48 + 45) u B^2) -- still far inside the 256 u B^2 of the
+//     threshold (256 (1 - 11 u) > 93).  B >= |o|_1 + |c0| + |r| + |dc| |f| as everywhere (segs[6], segs[7]).
+// Stage two then runs, per lane, the test the wave-uniform loop would have run on the segment: the second form for 10 / 11 / 12,
+// the first form (screen_filter, centre folded into o - c) for 13 / 14 -- both proofs start from disc_ref > 0, which is all stage
+// one relies on.
 struct PlaneRay {   // per ray and closest-hit query
   double nx, nz;    // (-d~z, d~x)
   double w2;        // nx^2 + nz^2
@@ -232,6 +246,7 @@ struct PlaneSeg {   // per ray and segment
   double nx, nz;    // normal of the ground track (0 when everything is kept)
   double c0;        // -(n . o_xz)
   double negthr;    // -(R^2 (1 + 2^-40) + M~) w2; -inf: everything is kept
+  double fnx, fnz;  // f n (xkind 13); 0 when everything is kept
 };
 TOR_HD PlaneRay plane_ray(const ScreenRay& r) {
   PlaneRay pr;
@@ -251,6 +266,8 @@ TOR_HD PlaneSeg plane_seg(const ScreenRay& r, const PlaneRay& pr, double reach, 
   s.nz = all ? 0.0 : pr.nz;
   s.c0 = all ? 0.0 : -fma_(s.nx, r.ox, s.nz * r.oz);
   s.negthr = all ? -__builtin_inf() : -thr;
+  s.fnx = all ? 0.0 : f * s.nx;   // (a non-finite f: B and the threshold are not finite either -> `all`)
+  s.fnz = all ? 0.0 : f * s.nz;
   return s;
 }
 // the returned word's SIGN BIT is the decision (set = keep)
@@ -258,6 +275,25 @@ TOR_HD int plane_word(const PlaneSeg& s, double cx, double cz) {
   const double v = fma_(s.nx, cx, fma_(s.nz, cz, s.c0));
   const double q = fma_(v, v, s.negthr);
   return (int)(unsigned)(double_to_bits(q) >> 32);
+}
+// xkind 13: record {c0x, c0z, dcx, dcz}
+TOR_HD int plane_word_mov(const PlaneSeg& s, double c0x, double c0z, double dcx, double dcz) {
+  const double v = fma_(s.nx, c0x, fma_(s.nz, c0z, fma_(s.fnx, dcx, fma_(s.fnz, dcz, s.c0))));
+  const double q = fma_(v, v, s.negthr);
+  return (int)(unsigned)(double_to_bits(q) >> 32);
+}
+// Does stage one PAY on this segment for this ray?  It leaves the objects in a band of half-width R around the ground track to a
+// per-lane stage that costs ~8 times a wave-uniform test per object, so it only pays when the band is thin against the segment:
+// a wall of spheres seen edge-on (every centre on the ray's own ground track) would send everything through both stages.  The
+// centres' bounding box in xz has extents (Sx, Sz) (host: xsegs[5], xsegs[6]); its width across the track is at most
+// E = (|nx| Sx + |nz| Sz) / |n|, and the share of a uniformly filled box inside the band about 2 R / E.  The plane runs when that
+// estimate is below 1 / kPlaneGate; the wave takes the majority's vote (the loop is wave-uniform).  A performance decision only:
+// either way every object meets a conservative test and every candidate the exact one.
+// (gate2 = 4 kPlaneGate^2 travels in KParams; 0 = no gate -- TOR_PLANE=2, the yardstick of the gate itself)
+constexpr double kPlaneGate = 16.0;
+TOR_HD bool plane_pays(const PlaneRay& pr, double gate2, double rmax2, double sx, double sz) {
+  const double e = fma_(__builtin_fabs(pr.nx), sx, __builtin_fabs(pr.nz) * sz);
+  return !pr.all && (gate2 * rmax2) * pr.w2 < e * e;
 }
 
 }  // namespace tor
