@@ -183,7 +183,10 @@ enum {
   TOR_ERR_INVALID_ARGUMENT = -1,
   TOR_ERR_NO_DEVICE = -2,  /* no HIP device / kernels unavailable: there is NO CPU fallback */
   TOR_ERR_HIP = -3,
-  TOR_ERR_OUT_OF_MEMORY = -4
+  TOR_ERR_OUT_OF_MEMORY = -4,
+  TOR_ERR_INCOMPLETE = -5  /* tor_last_kernel_ms after an asynchronous tor_render_device whose chain hand-off stalled: the frame
+                              has holes and must be rendered again (the blocking entry points and tor_render_gather_device
+                              do that themselves)                                                                     */
 };
 
 /* ------------------------------------------------------------------------------------ */

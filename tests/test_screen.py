@@ -140,6 +140,19 @@ def test_screen_degenerate_rays(tor):
         keep2, need2 = tor.selftest_screen2(o, d, c0, dc, moving, f, r2, variant)
         assert np.all((need2 == 0) | (keep2 != 0)), (variant, keep2, need2)
         assert keep2[1] and keep2[2]
+    # a camera INSIDE a sphere so far from the origin that |c|^2 overflows (K = +inf on the host, clamped) -- o - c is
+    # small, the reference hits it, the ray is wild for the second form (B^2 overflows) and must keep the object, not produce
+    # 0 x inf = NaN of whatever sign
+    c_far = np.array([[2e154, 0.0, 0.0], [0.0, -3e154, 1e154], [1e155, 1e155, 1e155]])
+    o_far = c_far + np.array([[1e138, 0, 0], [0, 2e138, 0], [0, 0, -1e139]])
+    d_far = np.array([[1.0, 0.2, 0.1], [0.0, 1.0, 0.0], [0.3, 0.3, 1.0]])
+    r2_far = np.full(3, 1e300)                                  # radius 1e150: the camera is deep inside
+    z3, zi, zf = np.zeros((3, 3)), np.zeros(3, dtype=np.int32), np.zeros(3)
+    keep, need = tor.selftest_screen(o_far, d_far, c_far, z3, zi, zf, r2_far)
+    assert np.all(need != 0) and np.all(keep != 0), (keep, need)
+    for variant in (0, 1, 2):
+        keep2, need2 = tor.selftest_screen2(o_far, d_far, c_far, z3, zi, zf, r2_far, variant)
+        assert np.all(need2 != 0) and np.all(keep2 != 0), (variant, keep2, need2)
 
 
 

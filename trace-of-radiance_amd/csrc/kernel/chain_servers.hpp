@@ -164,6 +164,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
             sig = __hip_atomic_load(p.work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
                   __hip_atomic_load(p.mig + kMigTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
                   __hip_atomic_load(p.mig + kMigServed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                  __hip_atomic_load(p.mig + kMigProgress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
                   (__hip_atomic_load(p.mig + kMigLaneWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 40);
           }
           sig = bcast_first_u64(sig);
@@ -430,6 +431,7 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
         if (absorbed) break;  // render.nim:38
       }
       acc = acc + radiance;  // render.nim:67
+      if (p.mig_stall_ticks != 0 && lane == 0) __hip_atomic_fetch_add(p.mig + kMigProgress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // heartbeat (stall detector)
     }
     __builtin_amdgcn_s_setprio(0);
     double* out = p.out + (size_t)pl * 3;  // every lane holds the same sum

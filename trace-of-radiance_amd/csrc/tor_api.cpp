@@ -1080,6 +1080,16 @@ int tor_last_kernel_ms(TorContext* ctx, float* ms_out, int64_t* samples_out) {
   HIP_TRY(hipEventSynchronize(ctx->ev_stop[slot]));
   HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev_start[slot], ctx->ev_stop[slot]));
   if (samples_out) *samples_out = ctx->last_samples;
+  // an asynchronous caller that comes here to learn that its launch is over also learns when the frame is NOT whole
+  // (ADVICE r4): the hand-off's stall escape leaves holes, and only tor_context_handoff_stalled used to say so
+  if (ctx->last_migrate && slot == ctx->last_slot) {
+    unsigned long long w = 0;
+    HIP_TRY(hipMemcpy(&w, (unsigned long long*)ctx->counters.ptr + (size_t)slot * TorContext::kSlotWords + TorContext::kMigWord0 + tor::kMigStalled,
+                      sizeof w, hipMemcpyDeviceToHost));
+    if (w != 0)
+      return fail(TOR_ERR_INCOMPLETE, "tor_last_kernel_ms: the launch's chain hand-off stalled (not all of its workgroups were resident) and flagged the "
+                                      "frame INCOMPLETE -- render it again (tor_context_handoff_stalled; the blocking entry points do so themselves)");
+  }
   return TOR_OK;
 }
 

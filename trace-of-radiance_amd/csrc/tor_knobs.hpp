@@ -30,7 +30,6 @@ constexpr Knob kKnobs[] = {
     // ---- multi-GPU gather: watchdog and test hooks ----
     {"TOR_RCCL_TIMEOUT_MS", "10000 + 1 per MB", "> 0", "call", "deadline of one RCCL framebuffer transfer; past it the communicators are aborted and TOR_GATHER=auto carries on with peer copies"},
     {"TOR_RCCL_INIT_TIMEOUT_MS", "120000", "> 0", "call", "deadline of communicator creation + self-check (runs in a helper thread that is abandoned when it does not return)"},
-    {"TOR_RCCL_DRAIN_MS", "5000", "> 0", "call", "how long the streams may take to become idle after an abort"},
     {"TOR_FAULT_INJECT", "(none)", "comma list of rccl_init | rccl_xfer | rccl_hang | peer", "call", "TEST: the named gather leg fails (or, rccl_hang, never completes) at that point"},
     {"TOR_COPY_CHUNK_KB", "2048", "> 0", "call", "chunk size of the pinned D2H staging of a host canvas"},
     {"TOR_COPY_THREADS", "8", ">= 1", "call", "host threads that move staged chunks into the caller's canvas"},

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -171,6 +172,9 @@ namespace {
 
 std::mutex g_comm_mutex;
 std::map<std::vector<int>, std::vector<ncclComm_t>> g_single_process_comms;  // per device list (ncclCommInitAll)
+struct CommSetup;
+std::map<std::vector<int>, std::shared_ptr<CommSetup>> g_comm_pending;       // creations in flight (helper threads), guarded by g_comm_mutex
+std::set<std::vector<int>> g_comm_timed_out;                                  // lists whose creation passed its deadline once
 
 int shard_max_rows(int32_t nrows, int32_t row_tile, int32_t count) {
   int m = 0;
@@ -324,14 +328,23 @@ long env_ms(const char* name, long dflt) {
 }
 
 // all streams idle -> hipSuccess; past the deadline -> hipErrorNotReady; a stream in error -> that error
-hipError_t wait_streams(const std::vector<TorContext*>& ctxs, long deadline_ms) {
+// (device, stream) of one participant of a gather: a context's own render stream, or -- the communicator's self-check, which
+// may run in a helper thread that the caller has given up on -- a private stream that no render ever touches
+struct GatherLane { int device; hipStream_t stream; };
+std::vector<GatherLane> lanes_of(const std::vector<TorContext*>& ctxs) {
+  std::vector<GatherLane> l;
+  for (TorContext* c : ctxs) l.push_back({c->device, c->stream});
+  return l;
+}
+
+hipError_t wait_streams(const std::vector<GatherLane>& ctxs, long deadline_ms) {
   using clk = std::chrono::steady_clock;
   const clk::time_point t0 = clk::now();
   size_t k = 0;
   unsigned spins = 0;
   while (k < ctxs.size()) {
-    hipError_t e = hipSetDevice(ctxs[k]->device);
-    if (e == hipSuccess) e = hipStreamQuery(ctxs[k]->stream);
+    hipError_t e = hipSetDevice(ctxs[k].device);
+    if (e == hipSuccess) e = hipStreamQuery(ctxs[k].stream);
     if (e == hipSuccess) { ++k; continue; }
     if (e != hipErrorNotReady) return e;
     (void)hipGetLastError();
@@ -359,10 +372,10 @@ constexpr int TOR_RCCL_TIMED_OUT = -1000;  // internal: rccl_group_gather's dead
 
 // One grouped send/recv gather over the communicators of a single-process device list.  EVERY path out of here
 // closes the group; the streams are idle on TOR_OK and on every error except TOR_RCCL_TIMED_OUT.
-int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<TorContext*>& ctxs, const std::vector<const void*>& src,
+int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<GatherLane>& ctxs, const std::vector<const void*>& src,
                       const std::vector<size_t>& bytes, char* dst_base, size_t dst_stride, bool inject_failure, HangInjection* hang) {
   const int N = (int)ctxs.size();
-  TorContext* root = ctxs[0];
+  const GatherLane* root = &ctxs[0];
   ncclResult_t first = ncclSuccess;
   const char* where = "";
   auto note = [&](ncclResult_t r, const char* w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; where = w; } };
@@ -377,7 +390,7 @@ int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::v
     for (int k = 1; k < N && first == ncclSuccess; ++k) {
       if (bytes[(size_t)k] == 0) continue;
       if (inject_failure && k == N - 1) { note(ncclInternalError, "TOR_FAULT_INJECT=rccl_xfer"); break; }
-      note(api->Send(src[(size_t)k], bytes[(size_t)k], ncclChar, 0, comms[(size_t)k], ctxs[(size_t)k]->stream), "ncclSend");
+      note(api->Send(src[(size_t)k], bytes[(size_t)k], ncclChar, 0, comms[(size_t)k], ctxs[(size_t)k].stream), "ncclSend");
       if (first != ncclSuccess) break;
       note(api->Recv(dst_base + (size_t)k * dst_stride, bytes[(size_t)k], ncclChar, k, comms[0], root->stream), "ncclRecv");
     }
@@ -396,26 +409,30 @@ int rccl_group_gather(RcclApi* api, std::vector<ncclComm_t>& comms, const std::v
   return TOR_OK;
 }
 
+constexpr long kRcclDrainMs = 5000;  // how long the streams may take to become idle after an abort
+
 // after a timed-out transfer: abort, then give the streams a moment to drain so that the next leg finds them idle
-void abort_comms(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<TorContext*>& ctxs, HangInjection* hang) {
+void abort_comms(RcclApi* api, std::vector<ncclComm_t>& comms, const std::vector<GatherLane>& ctxs, HangInjection* hang) {
   if (hang) hang->release();
   if (api && api->CommAbort)
     for (ncclComm_t& c : comms)
       if (c) { (void)api->CommAbort(c); c = nullptr; }
-  (void)wait_streams(ctxs, env_ms("TOR_RCCL_DRAIN_MS", 5000));
-  (void)hipSetDevice(ctxs[0]->device);
+  (void)wait_streams(ctxs, kRcclDrainMs);
+  (void)hipSetDevice(ctxs[0].device);
 }
 
 // ncclCommInitAll + self-check for one device list; runs in its own thread (see the watchdog comment).  Everything it
-// touches is owned by this object.
+// touches is owned by this object -- the self-check's buffers and STREAMS included (it used to run on the contexts'
+// render streams, which the caller is rendering on again once it has given up on this thread).
 struct CommSetup {
   std::mutex m;
   std::condition_variable cv;
   bool done = false;
+  std::atomic<bool> abandoned{false};  // the caller's deadline passed: publish nothing, destroy what was created, touch nothing shared
   int rc = TOR_OK;
   std::string err;
   std::vector<int> key;
-  std::vector<TorContext*> ctxs;   // default contexts: they live as long as the process
+  std::vector<int> devices;        // HIP ordinal of every entry of the list
   std::vector<ncclComm_t> comms;
 };
 
@@ -426,32 +443,46 @@ void comm_setup_body(std::shared_ptr<CommSetup> st) {
   std::vector<ncclComm_t> c((size_t)N, nullptr);
   const ncclResult_t r = api->CommInitAll(c.data(), N, st->key.data());
   if (r != ncclSuccess) check = fail_rccl(r, "ncclCommInitAll");
-  // self-check: device k sends kCheck bytes of value (k * 37 + i) & 0xff through the very same grouped send/recv code
+  auto drop = [&]() {  // nobody will ever use these communicators
+    for (ncclComm_t& cc : c)
+      if (cc) {
+        if (api->CommAbort) (void)api->CommAbort(cc);
+        else (void)api->CommDestroy(cc);
+        cc = nullptr;
+      }
+  };
+  if (st->abandoned.load()) { drop(); return; }
+  // self-check: device k sends kCheck bytes of value (k * 37 + i) & 0xff through the very same grouped send/recv code, on
+  // streams of its own
   constexpr size_t kCheck = 4096;
   std::vector<DeviceBuffer> pat((size_t)N);
   DeviceBuffer got;
   std::vector<const void*> src((size_t)N, nullptr);
   std::vector<size_t> bytes((size_t)N, kCheck);
   std::vector<unsigned char> host(kCheck);
+  std::vector<GatherLane> lanes;
   for (int k = 0; k < N && check == TOR_OK; ++k) {
     for (size_t i = 0; i < kCheck; ++i) host[i] = (unsigned char)((k * 37 + (int)i) & 0xff);
-    hipError_t e = hipSetDevice(st->ctxs[(size_t)k]->device);
+    hipStream_t s = nullptr;
+    hipError_t e = hipSetDevice(st->devices[(size_t)k]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) lanes.push_back({st->devices[(size_t)k], s});
     if (e == hipSuccess) e = pat[(size_t)k].ensure(kCheck);
     if (e == hipSuccess) e = hipMemcpy(pat[(size_t)k].ptr, host.data(), kCheck, hipMemcpyHostToDevice);
-    if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: pattern upload");
+    if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: stream / pattern upload");
     src[(size_t)k] = pat[(size_t)k].ptr;
   }
   if (check == TOR_OK) {
-    hipError_t e = hipSetDevice(st->ctxs[0]->device);
+    hipError_t e = hipSetDevice(st->devices[0]);
     if (e == hipSuccess) e = got.ensure(kCheck * (size_t)N);
     if (e == hipSuccess) e = hipMemset(got.ptr, 0, kCheck * (size_t)N);
     if (e != hipSuccess) check = fail_hip(e, "RCCL self-check: receive buffer");
   }
   if (check == TOR_OK) {
-    check = rccl_group_gather(api, c, st->ctxs, src, bytes, (char*)got.ptr, kCheck, false, nullptr);
+    check = rccl_group_gather(api, c, lanes, src, bytes, (char*)got.ptr, kCheck, false, nullptr);
     if (check == TOR_RCCL_TIMED_OUT) {
       const std::string why = tor_last_error();
-      abort_comms(api, c, st->ctxs, nullptr);
+      abort_comms(api, c, lanes, nullptr);
       check = fail(TOR_ERR_HIP, "RCCL self-check: " + why);
     }
   }
@@ -468,10 +499,14 @@ void comm_setup_body(std::shared_ptr<CommSetup> st) {
   }
   for (DeviceBuffer& b : pat) b.release();
   got.release();
-  if (check != TOR_OK)
-    for (ncclComm_t& cc : c)
-      if (cc) { (void)api->CommDestroy(cc); cc = nullptr; }
+  for (const GatherLane& l : lanes)
+    if (hipSetDevice(l.device) == hipSuccess) (void)hipStreamDestroy(l.stream);
+  if (check != TOR_OK) drop();
   std::lock_guard<std::mutex> lock(st->m);
+  if (st->abandoned.load()) {  // (the flag is set under st->m: checked here, nothing can be published to a caller that has left)
+    drop();
+    return;
+  }
   st->rc = check;
   if (check != TOR_OK) st->err = tor_last_error();
   else st->comms = std::move(c);
@@ -499,22 +534,48 @@ int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
   if (fault.rccl_hang) {
     comms = &no_comms;
   } else {
-    std::lock_guard<std::mutex> lock(g_comm_mutex);
-    auto it = g_single_process_comms.find(j.key);
-    if (it == g_single_process_comms.end()) {
-      auto st = std::make_shared<CommSetup>();
-      st->key = j.key;
-      st->ctxs = ctxs;
-      std::thread(comm_setup_body, st).detach();
-      const long deadline = env_ms("TOR_RCCL_INIT_TIMEOUT_MS", 120000);
-      std::unique_lock<std::mutex> wait_lock(st->m);
-      if (!st->cv.wait_for(wait_lock, std::chrono::milliseconds(deadline), [&] { return st->done; }))
-        return fail(TOR_ERR_HIP, "RCCL: communicator creation + self-check did not return within " + std::to_string(deadline) +
-                                     " ms (TOR_RCCL_INIT_TIMEOUT_MS); abandoned");
-      if (st->rc != TOR_OK) return fail(st->rc, st->err);
-      it = g_single_process_comms.emplace(j.key, std::move(st->comms)).first;
+    // The creation thread is waited for WITHOUT the registry's mutex (up to 120 s during which no other thread could
+    // even look a communicator up); callers that ask for the same list meanwhile wait on the same CommSetup.  A list whose
+    // creation timed out once is remembered: an explicit TOR_GATHER=rccl does not leave another hung thread behind per call.
+    std::shared_ptr<CommSetup> st;
+    {
+      std::lock_guard<std::mutex> lock(g_comm_mutex);
+      auto it = g_single_process_comms.find(j.key);
+      if (it != g_single_process_comms.end()) comms = &it->second;
+      else if (g_comm_timed_out.count(j.key))
+        return fail(TOR_ERR_HIP, "RCCL: communicator creation for this device list timed out earlier in this process; not tried again");
+      else {
+        auto pend = g_comm_pending.find(j.key);
+        if (pend != g_comm_pending.end()) st = pend->second;
+        else {
+          st = std::make_shared<CommSetup>();
+          st->key = j.key;
+          for (TorContext* c : ctxs) st->devices.push_back(c->device);
+          g_comm_pending[j.key] = st;
+          std::thread(comm_setup_body, st).detach();
+        }
+      }
     }
-    comms = &it->second;
+    if (!comms) {
+      const long deadline = env_ms("TOR_RCCL_INIT_TIMEOUT_MS", 120000);
+      bool finished;
+      {
+        std::unique_lock<std::mutex> wait_lock(st->m);
+        finished = st->cv.wait_for(wait_lock, std::chrono::milliseconds(deadline), [&] { return st->done; });
+        if (!finished) st->abandoned.store(true);   // under st->m: the thread checks it under the same mutex before publishing
+      }
+      std::lock_guard<std::mutex> lock(g_comm_mutex);
+      g_comm_pending.erase(j.key);
+      if (!finished) {
+        g_comm_timed_out.insert(j.key);
+        return fail(TOR_ERR_HIP, "RCCL: communicator creation + self-check did not return within " + std::to_string(deadline) +
+                                     " ms (TOR_RCCL_INIT_TIMEOUT_MS); abandoned (the helper thread destroys whatever it still creates)");
+      }
+      if (st->rc != TOR_OK) return fail(st->rc, st->err);
+      auto it = g_single_process_comms.find(j.key);
+      if (it == g_single_process_comms.end()) it = g_single_process_comms.emplace(j.key, std::move(st->comms)).first;   // (the first of several waiters publishes)
+      comms = &it->second;
+    }
   }
   HIP_TRY(hipSetDevice(root->device));
   char* gbase = (char*)root->gather.ptr;
@@ -524,10 +585,11 @@ int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
   std::vector<size_t> bytes((size_t)N, 0);
   for (int k = 0; k < N; ++k) { src[(size_t)k] = ctxs[(size_t)k]->scratch.ptr; bytes[(size_t)k] = j.shard_bytes(k); }
   HangInjection hang;
-  rc = rccl_group_gather(api, *comms, ctxs, src, bytes, gbase, j.slot_bytes(), fault.rccl_xfer, fault.rccl_hang ? &hang : nullptr);
+  const std::vector<GatherLane> lanes = lanes_of(ctxs);
+  rc = rccl_group_gather(api, *comms, lanes, src, bytes, gbase, j.slot_bytes(), fault.rccl_xfer, fault.rccl_hang ? &hang : nullptr);
   if (rc == TOR_RCCL_TIMED_OUT) {
     const std::string why = tor_last_error();
-    abort_comms(api, *comms, ctxs, fault.rccl_hang ? &hang : nullptr);
+    abort_comms(api, *comms, lanes, fault.rccl_hang ? &hang : nullptr);
     if (!fault.rccl_hang) {
       std::lock_guard<std::mutex> lock(g_comm_mutex);
       g_single_process_comms.erase(j.key);  // (aborted communicators are gone)
@@ -812,6 +874,14 @@ int tor_render_gather_device(TorContext* ctx, const TorCamera* cam, int32_t nrow
   HIP_TRY(ctx->scratch.ensure(slot_bytes));
   int rc = tor_render_device(ctx, cam, nrows, ncols, spp, gamma_correction, max_depth, &o, (double*)ctx->scratch.ptr, stream);
   if (rc != TOR_OK) return rc;
+  // A chain hand-off launch may flag itself INCOMPLETE (the stall escape of a launch that is not fully resident): such a shard
+  // must not be gathered.  For those launches -- SEED_PIXEL with both accelerations, nothing else -- the call waits
+  // for the shard and renders it again without the hand-off when the flag is set, as the blocking entry points do; every
+  // other launch stays asynchronous.
+  if (ctx->last_migrate) {
+    rc = tor::rerender_if_stalled(ctx, cam, nrows, ncols, spp, gamma_correction, max_depth, &o, (double*)ctx->scratch.ptr, stream);
+    if (rc != TOR_OK) return rc;
+  }
   const double* gathered = (const double*)ctx->scratch.ptr;
   if (world > 1) {
     tor::RcclApi* api = tor::rccl();

@@ -161,7 +161,10 @@ TOR_HD ScreenSeg screen2_seg(const ScreenRay& r, double reach, double travel, do
   s.Tn = wild ? -__builtin_inf() : -(sg2 * (M - Q));
   const double n2 = wild ? 0.0 : -(sg2 + sg2);
   s.a2x = n2 * r.ox; s.a2y = n2 * oy; s.a2z = n2 * r.oz;
-  s.ks = sg2;
+  // (a wild ray keeps EVERYTHING: Tn = -inf and every factor 0 -- ks included, with K clamped to a finite value by the host
+  // (screen2_K), so that no 0 x inf = NaN of unspecified sign can come out of the chain: ADVICE r4 -- a camera inside a sphere
+  // 1e155 from the origin is hit by the reference, |c|^2 overflows, and the `keeps everything` promise must hold for it)
+  s.ks = wild ? 0.0 : sg2;
   s.fdy = f * s.hy;
   s.gn = f * s.a2y;
   s.f2n = wild ? 0.0 : sg2 * (f * f);
@@ -198,8 +201,11 @@ TOR_HD int screen2_movy_y(const ScreenSeg& s, double cx, double cz, double K, do
   return screen2_word(nh, tn);
 }
 // the host's side of the records (tor_scene.cpp build_layout; the self test)
-TOR_HD double screen2_K(double cx, double cy, double cz, double r2) { return ((cx * cx + cy * cy) + cz * cz) - r2; }
-TOR_HD double screen2_Ky(double cx, double cz, double r2) { return (cx * cx + cz * cz) - r2; }
+// (clamped to the finite range: +-inf would meet the wild ray's zero factors as NaN; a NaN K -- a NaN centre or radius, which the
+// reference can never hit -- becomes -max (fmax skips the NaN): kept by the screen, rejected by the exact test)
+TOR_HD double screen2_clampK(double k) { return __builtin_fmin(__builtin_fmax(k, -0x1.fffffffffffffp1023), 0x1.fffffffffffffp1023); }
+TOR_HD double screen2_K(double cx, double cy, double cz, double r2) { return screen2_clampK(((cx * cx + cy * cy) + cz * cz) - r2); }
+TOR_HD double screen2_Ky(double cx, double cz, double r2) { return screen2_clampK((cx * cx + cz * cz) - r2); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // STAGE ONE in front of the second form (round 4, kinds 11 and 12): the PLANE screen.  A sphere can only be hit by a ray whose
