@@ -249,7 +249,10 @@ def test_strict_layout_walk_on_the_host(tor):
         elif i % 3 == 1: cloud.append([1, x, y, z, x, y + rng.uniform(0, .5), z, 0.0, 1.0, r, 0, .5, .5, .5, 0, 0])
         else: cloud.append([1, x, y, z, x + rng.uniform(-.4, .4), y + rng.uniform(-.3, .3), z + rng.uniform(-.4, .4), 0.0, 1.0, r, 0, .5, .5, .5, 0, 0])
     cloud = np.asarray(cloud, dtype=np.float64)
-    for recs_k, want_kinds in ((recs, {10, 11, 12}), (mixed, {0, 10, 11, 12, 13, 14}), (cloud, {10, 13, 14})):   # (mixed: the 5 movers along y at 0.3 are below a segment's 8 -> xkind 14)
+    # (round 5: statics resting at the common height of a segment of movers along y join it -- random_scene's 86 small statics are
+    # xkind 12 now, and so are `mixed`'s 41 statics at 0.2; its 19 statics at 0.4 stay 11: the movers at 0.4 have another radius class? no --
+    # they join too when the radii are of one class, which `add` draws per object: asserted loosely below)
+    for recs_k, want_kinds in ((recs, {10, 12}), (mixed, None), (cloud, {10, 13, 14})):   # (mixed: the 5 movers along y at 0.3 are below a segment's 8 -> xkind 14)
         scene = tor.Scene.from_records(recs_k)
         n_obj = len(recs_k)
         n_rays = 400
@@ -264,12 +267,15 @@ def test_strict_layout_walk_on_the_host(tor):
         d[:4] = [[0, -1, 0], [0, 1, 0], [1e-200, -1, 0], [0, -1, 1e-40]]   # vertical: no ground track
         t = rng.uniform(-0.2, 1.2, n_rays)
         keep, kind, pays = tor.debug_screen2_scene(scene.list(), o, d, t, max_segs=16)
-        assert set(np.unique(kind)) == want_kinds, np.unique(kind)
+        if want_kinds is not None:
+            assert set(np.unique(kind)) == want_kinds, np.unique(kind)
+        else:
+            assert {0, 10, 12, 13, 14} <= set(np.unique(kind)) <= {0, 10, 11, 12, 13, 14}, np.unique(kind)
         is_static = recs_k[:, 0] == 0
         y_mover = (~is_static) & (recs_k[:, 4] == recs_k[:, 1]) & (recs_k[:, 6] == recs_k[:, 3])
         degenerate = (~is_static) & (recs_k[:, 7] == recs_k[:, 8])
         assert np.all(kind[degenerate] == 0) and np.all(kind[~degenerate] >= 10)
-        assert np.all(kind[~is_static & ~y_mover & ~degenerate] == 13) and np.all(np.isin(kind[is_static], (10, 11)))
+        assert np.all(kind[~is_static & ~y_mover & ~degenerate] == 13) and np.all(np.isin(kind[is_static], (10, 11, 12)))
         assert np.all(np.isin(kind[y_mover & ~degenerate], (12, 14)))
         assert np.all((keep == 3) == (kind == 0)[None, :])
         assert np.all(pays[4:, 0] >= 0)                                # a vote per ray and segment

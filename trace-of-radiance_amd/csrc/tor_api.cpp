@@ -752,6 +752,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
   const tor::HostAccel& hacc = *hacc_p;
   std::vector<double>& bnd_host = ctx->bnd_host[slot];
   p.nrows = nrows; p.ncols = ncols; p.spp = spp; p.max_depth = (int)max_depth;
+  p.inv_spp = 1.0 / (double)spp; p.inv_ncols = 1.0 / (double)ncols; p.inv_row_tile = 1.0 / (double)(o.row_tile > 0 ? o.row_tile : 1);
   p.shard_index = o.shard_index; p.shard_count = o.shard_count; p.row_tile = o.row_tile;
   p.work_counter = slot_counters;
   p.stats = ctx->collect_stats ? slot_counters + 1 : nullptr;
@@ -831,6 +832,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       }
     }
     pp.spp = ctx->probe_spp;
+    pp.inv_spp = 1.0 / (double)ctx->probe_spp;
     pp.total_work = (unsigned long long)npix * (unsigned long long)ctx->probe_spp;
     ctx->last_probe_pixels = npix;
     pp.chunk = 256;

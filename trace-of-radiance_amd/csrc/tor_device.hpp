@@ -14,6 +14,12 @@
 
 namespace tor {
 
+// floor(n / d) for a 32-bit n and a divisor d >= 1 whose float64 reciprocal inv = 1.0 / d (correctly rounded, from the host) is at
+// hand: (n + 0.5) * inv, truncated -- 4 instructions instead of the ~22 of a 32-bit division by a run-time divisor.  Exact: with
+// q = floor(n / d) the quotient (n + 0.5) / d lies in [q + 0.5 / d, q + 1 - 0.5 / d]; n + 0.5 is exact in float64, inv and the
+// product carry a relative error below 2^-52 together, i.e. an absolute one below (2^32 / d + 1) 2^-52 < 0.5 / d for every d < 2^32.
+TOR_HD unsigned udiv_by(unsigned n, double inv) { return (unsigned)(((double)n + 0.5) * inv); }
+
 struct V3 {
   double x, y, z;
 };

@@ -706,6 +706,8 @@ static IntegrateFn integrate_variant(int seeding, int arith, int w, int f32, int
   TOR_V4(2, 0, 3)   // cost probe of the SEED_PIXEL tile schedule
   // arith 2: the reference's arithmetic behind the conservative FMA screen (brute-force layouts only)
   TOR_V(0, 2, 2, 0, 0) TOR_V(0, 2, 3, 0, 0) TOR_V(1, 2, 2, 0, 0) TOR_V(1, 2, 3, 0, 0) TOR_V(2, 2, 3, 0, 0)
+  // (round 5: a 128-register build <1, 2, 4, 0, 0> for a 4th workgroup per CU now runs 2.4 x SLOWER -- 1097 against 2613 Msamples/s
+  // at configs[1]: stage two's per-lane state spills inside the loops; not built)
   // (a 128-register build of <1, 2, W, 0, 0> for a 4th workgroup per CU was measured in round 4: 1951 against 1961 Msamples/s at
   // configs[2] for 3 workgroups -- tools/wpc_sweep.py, profiles/r4_wpc_sweep.txt -- and is not built)
 #undef TOR_V4

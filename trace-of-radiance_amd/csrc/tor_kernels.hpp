@@ -69,6 +69,7 @@ struct KParams {
                        // entries have no block boxes / records behind them and must never be entered)
   int n_segs;
   int nrows, ncols, spp, max_depth;
+  double inv_spp, inv_ncols, inv_row_tile;  // 1.0 / spp, 1.0 / ncols, 1.0 / row_tile for udiv_by (tor_device.hpp)
   int shard_index, shard_count, row_tile;
   unsigned chunk;   // SEED_SAMPLE: largest chunk of the guided schedule
   unsigned n_waves; // waves launched

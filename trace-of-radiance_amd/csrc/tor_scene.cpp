@@ -240,6 +240,38 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     if (!gy.ids.empty()) cut_by_y(gy.ids, 1, t0, dt, sane ? 14 : 0, sane ? 12 : 0);
     if (!gg.ids.empty()) cut_by_y(gg.ids, 2, t0, dt, sane ? 13 : 0, 0);
   }
+  // Statics that rest at the common height of a segment of movers along y JOIN that segment as movers that do not move
+  // (dc = 0: c0 + f * 0 == c0 exactly for every finite f; the cold record keeps them static, so the exact test never reads f).
+  // One segment instead of two: the per-segment set-up of the screened loop (margins, plane and second-form constants, a vote)
+  // is worth ~80 objects of stage one -- random_scene's 86 resting statics and 395 resting movers become one segment of 481.
+  // Only for radii of the same class (the plane screen's band is the largest radius of the segment).
+  for (size_t a = 0; a < segs64.size(); ++a) {
+    if (!(segs64[a].kind == 0 && segs64[a].xkind == 11)) continue;
+    for (size_t b = 0; b < segs64.size(); ++b) {
+      Seg64& mv = segs64[b];
+      if (!(mv.kind == 1 && mv.xkind == 12)) continue;
+      uint64_t ya, yb;
+      std::memcpy(&ya, &segs64[a].y, 8); std::memcpy(&yb, &mv.y, 8);
+      if (ya != yb) continue;
+      double ra = 0.0, rb = 0.0;
+      for (int64_t i : segs64[a].ids) ra = std::fmax(ra, r2_of(i));
+      for (int64_t i : mv.ids) rb = std::fmax(rb, r2_of(i));
+      if (!(ra <= 4.0 * rb && rb <= 4.0 * ra)) continue;
+      mv.ids.insert(mv.ids.end(), segs64[a].ids.begin(), segs64[a].ids.end());
+      segs64.erase(segs64.begin() + (long)a);
+      --a;
+      break;
+    }
+  }
+  // (a member of a mover segment as a mover: a static sphere that joined one is c0 == c1)
+  auto as_mover = [&](int64_t idx) {
+    if (objs[idx].kind == TOR_MOVING_SPHERE) return objs[idx].u.moving_sphere;
+    TorMovingSphere m{};
+    m.center0 = m.center1 = objs[idx].u.sphere.center;
+    m.radius = objs[idx].u.sphere.radius;
+    m.material = objs[idx].u.sphere.material;
+    return m;
+  };
   // float64 per slot of the second-stage records (xrec) and of the plane table (xpl), by xkind
   auto xs_of = [](int xkind) { return xkind == 0 ? 0 : (xkind >= 13 ? 8 : 4); };
   auto pw_of = [](int xkind) { return xkind == 0 ? 0 : (xkind == 13 ? 4 : 2); };
@@ -297,7 +329,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
         rmax2 = std::fmax(rmax2, s.radius * s.radius);
         grow(s.center.x, s.center.z);
       } else {
-        const TorMovingSphere& s = objs[idx].u.moving_sphere;
+        const TorMovingSphere s = as_mover(idx);
         reach = std::fmax(reach, norm3(s.center0.x, s.center0.y, s.center0.z) + std::fabs(s.radius));
         rmax2 = std::fmax(rmax2, s.radius * s.radius);
         travel = std::fmax(travel, norm3(s.center1.x - s.center0.x, s.center1.y - s.center0.y, s.center1.z - s.center0.z));
@@ -337,7 +369,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
         else { x[0] = s.center.x; x[1] = s.center.z; x[2] = screen2_Ky(s.center.x, s.center.z, s.radius * s.radius); x[3] = 0.0; }
         out.xpl[pl_off + 2 * k] = s.center.x; out.xpl[pl_off + 2 * k + 1] = s.center.z;
       } else {
-        const TorMovingSphere& s = hv.u.moving_sphere;
+        const TorMovingSphere s = as_mover(sg.ids[k]);
         const double dcx = s.center1.x - s.center0.x, dcy = s.center1.y - s.center0.y, dcz = s.center1.z - s.center0.z;
         if (sg.kind == 1) {
           double* m = &out.movy[6 * (movy_rec + k)];

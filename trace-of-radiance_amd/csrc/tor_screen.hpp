@@ -165,9 +165,10 @@ TOR_HD ScreenSeg screen2_seg(const ScreenRay& r, double reach, double travel, do
   // (screen2_K), so that no 0 x inf = NaN of unspecified sign can come out of the chain: ADVICE r4 -- a camera inside a sphere
   // 1e155 from the origin is hit by the reference, |c|^2 overflows, and the `keeps everything` promise must hold for it)
   s.ks = wild ? 0.0 : sg2;
-  s.fdy = f * s.hy;
-  s.gn = f * s.a2y;
-  s.f2n = wild ? 0.0 : sg2 * (f * f);
+  const double fw = wild ? 0.0 : f;   // (a non-finite f makes B, hence the ray, wild: no inf x 0 in the factors below)
+  s.fdy = fw * s.hy;
+  s.gn = fw * s.a2y;
+  s.f2n = sg2 * (fw * fw);
   return s;
 }
 // the per-object tests; the returned word's SIGN BIT is the decision (set = keep), as screen_filter's
