@@ -431,7 +431,10 @@ __device__ __forceinline__ bool serve_chains(const KParams& p, bool dedicated) {
         if (absorbed) break;  // render.nim:38
       }
       acc = acc + radiance;  // render.nim:67
-      if (p.mig_stall_ticks != 0 && lane == 0) __hip_atomic_fetch_add(p.mig + kMigProgress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // heartbeat (stall detector)
+      // heartbeat for the stall detector, every 64th sample of the chain: at the end of a frame every wave of the machine serves, and
+      // one atomic per sample from each of them on one address cost the tail 100 ms of a 520 ms frame (measured, round 5); a
+      // finished chain moves kMigServed anyway
+      if (p.mig_stall_ticks != 0 && lane == 0 && (s & 63) == 63) __hip_atomic_fetch_add(p.mig + kMigProgress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_setprio(0);
     double* out = p.out + (size_t)pl * 3;  // every lane holds the same sum

@@ -125,7 +125,7 @@ enum : int {
   kMigItsTail = 72,
   kMigTCounterDry = 73,  // first wave that found the work counter dry
   kMigConverted = 74,  // dedicated server waves that turned into lane waves
-  kMigProgress = 75,   // heartbeat of work IN PROGRESS: a server bumps it per sample of the chain it serves, a lane wave every 4096th bounce iteration -- part of the stall detector's signature, so that a frame whose counters stand still while long chains are walked is not taken for a stalled one
+  kMigProgress = 75,   // heartbeat of work IN PROGRESS: a server bumps it every 64th sample of the chain it serves, a lane wave every 4096th bounce iteration -- part of the stall detector's signature, so that a frame whose counters stand still while long chains are walked is not taken for a stalled one
   kMigStalled = 95,    // a waiting server saw no progress of the frame for mig_stall_ticks and left holding a ticket: the canvas is INCOMPLETE (host: tor_api.cpp handoff_stalled)
   kMigPushNow = 80,    // line 5: the ADAPTIVE push threshold (lanes read it every bounce; idle servers lower it, pushers that meet a backlog raise it)
   kMigWords = 96
