@@ -435,11 +435,11 @@ def test_split_mode_lane_and_wave_kernels_share_a_frame(tor, oracle, ref_scene, 
 
 
 def test_pixel_schedule_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera):
-    """The TOR_SEED_PIXEL lane kernel's schedule (tiles ordered by their longest probed chain, two regions
-    of the order, slow wave slots retiring early, arbiter priorities) only decides WHO renders a pixel and WHEN.  A
-    frame large enough to occupy every hardware wave slot (> 3072 tiles, pixel count not a multiple of the tile) must
-    come out identical for every setting of the knobs -- including ones that push most of the work into region B,
-    make nearly every chain hot, or switch the machinery off -- and equal to the oracle."""
+    """The TOR_SEED_PIXEL lane kernel's schedule (tiles ordered by their longest probed chain, arbiter priorities) only
+    decides WHO renders a pixel and WHEN.  A frame large enough to occupy every hardware wave slot (> 3072 tiles, pixel count
+    not a multiple of the tile) must come out identical for every setting of the knobs -- including ones that make nearly
+    every chain hot or switch the machinery off -- and equal to the oracle.  (Round 5: the two-region cut of the order,
+    TOR_BACK_SLOT / TOR_TAIL_FRAC / TOR_BACK_ACCEL, is gone.)"""
     objs, _ = ref_scene
     scene, cam = tor.random_scene(0xFACADE), tor.camera()
     h, w, spp = 385, 515, 32
@@ -448,12 +448,8 @@ def test_pixel_schedule_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera
                      for r in rows])
     knobs = [
         {},
-        {"TOR_BACK_SLOT": "2", "TOR_TAIL_FRAC": "0.7", "TOR_HOT_FRAC": "0.02", "TOR_PRIO_SHIFT": "6"},
-        {"TOR_BACK_SLOT": "2"},                                # the two-region schedule as rounds 2-3 ran it by default
-        {"TOR_BACK_SLOT": "1", "TOR_TAIL_FRAC": "0.05"},
-        {"TOR_BACK_SLOT": "-1", "TOR_TAIL_FRAC": "0.3"},   # every wave takes itself for a slow-slot wave: region A must still be rendered
-        {"TOR_BACK_SLOT": "0", "TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0"},
-        {"TOR_BACK_SLOT": "2", "TOR_BACK_ACCEL": "1", "TOR_TAIL_FRAC": "0.5"},
+        {"TOR_HOT_FRAC": "0.02", "TOR_PRIO_SHIFT": "6"},
+        {"TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0"},
         {"TOR_LPT_MIN_SPP": "0"},
         {"TOR_BLOCKS_PER_CU": "2", "TOR_WAVES_PER_SIMD": "2"},
     ]

@@ -20,7 +20,7 @@ TOL = 1e-5
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HANDOFF_KNOBS = ("TOR_MIGRATE", "TOR_SRV_FRAC", "TOR_SRV_MIN_FRAC", "TOR_SRV_PATIENCE_US", "TOR_PUSH_THETA", "TOR_CHAIN_THETA", "TOR_FLOOR_THETA",
-                 "TOR_TAIL_LANES", "TOR_TAIL_REST", "TOR_MIG_FLAGS", "TOR_KEY_MODE", "TOR_BACK_SLOT", "TOR_TAIL_FRAC", "TOR_PROBE_ACCEL", "TOR_SCREEN")
+                 "TOR_TAIL_LANES", "TOR_TAIL_REST", "TOR_MIG_FLAGS", "TOR_SCREEN")
 
 
 def _exact(got, want):
@@ -78,7 +78,7 @@ def test_chain_handoff_never_changes_a_pixel(tor, oracle, ref_scene, ref_camera)
         {"TOR_SRV_MIN_FRAC": "0.3", "TOR_SRV_FRAC": "0.3", "TOR_TAIL_REST": "0", "TOR_SRV_PATIENCE_US": "100"},
         {"TOR_SRV_MIN_FRAC": "0.3", "TOR_SRV_FRAC": "0.3", "TOR_SRV_PATIENCE_US": "0"},
         {"TOR_MIG_FLAGS": "0x101"},                                       # acquire polling, no adaptive threshold
-        {"TOR_KEY_MODE": "0", "TOR_TAIL_LANES": "0"},
+        {"TOR_TAIL_LANES": "0"},
     ]
     pushed_some = False
     for env in settings:
@@ -203,44 +203,6 @@ def test_last_render_timing_means_what_the_header_says(tor):
     assert t["scene_cache_hit"] and t["upload_ms"] < 5.0
     assert t["render_ms"] > 50.0 and t["render_ms"] > 10.0 * t["download_ms"], t
     assert abs(t["upload_ms"] + t["render_ms"] + t["download_ms"] - t["total_ms"]) < 0.1 * t["total_ms"] + 1.0, t
-
-
-def test_schedule_with_empty_region_a_and_only_slow_slot_waves(tor, oracle, ref_scene, ref_camera):
-    """TOR_TAIL_FRAC >= 1 empties region A of the SEED_PIXEL schedule; with every wave treated as a slow-slot wave
-    (TOR_BACK_SLOT=-1) nobody fetched region B and the call returned stale pixels.  Now: no region B then, every tile rendered."""
-    import torch
-    objs, _ = ref_scene
-    scene, cam = tor.random_scene(0xFACADE), tor.camera()
-    h, w, spp = 72, 128, 40
-    want = oracle.render(h, w, spp, ref_camera, objs, seeding=0, math=1, arith=0).pixels
-    for env in ({"TOR_BACK_SLOT": "-1", "TOR_TAIL_FRAC": "1"}, {"TOR_BACK_SLOT": "-1", "TOR_TAIL_FRAC": "5"}, {"TOR_BACK_SLOT": "1", "TOR_TAIL_FRAC": "1"}):
-        got, _ = _render_with_env(tor, scene, cam, h, w, spp, env, seeding=tor.SEED_PIXEL, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE)
-        _exact(got.cpu().numpy(), want)
-
-
-def test_probe_runs_with_both_accelerations_in_front_of_a_brute_force_frame(tor):
-    """The cost probe counts closest-hit queries per pixel; how the hit is found does not change the count.  Same per-pixel
-    counts (exactly) and the same canvas whether the probe walks the frame's float64 layout or the culling layout."""
-    import torch
-    scene, cam = tor.random_scene(0xFACADE), tor.camera()
-    h, w, spp = 216, 384, 40
-    outs = []
-    for env in ({"TOR_PROBE_ACCEL": "0"}, {"TOR_PROBE_ACCEL": "1"}):
-        saved = os.environ.get("TOR_PROBE_ACCEL")
-        os.environ.update(env)
-        try:
-            ctx = tor.Context(0)
-        finally:
-            os.environ.pop("TOR_PROBE_ACCEL", None) if saved is None else os.environ.__setitem__("TOR_PROBE_ACCEL", saved)
-        ctx.upload(scene.list())
-        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
-        ctx.render_device(cam, h, w, spp, 2.2, 50, tor.make_options(seeding=tor.SEED_PIXEL, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE), buf.data_ptr(),
-                          torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        outs.append((buf, ctx.last_pixel_cost(h * w).copy()))
-        ctx.close()
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][1].sum() > 0
 
 
 def test_configs3_whole_frame_equals_its_eight_shares(tor):

@@ -6,7 +6,7 @@ Four workloads -- the bench scene and three others the tests already hold -- x {
 accelerations} x four settings of the scheduling machinery, every canvas compared with the first setting's:
 
     default        everything on
-    sched off      TOR_BACK_SLOT=0 TOR_HOT_FRAC=0 TOR_PRIO_SHIFT=0            (no regions, no priorities)
+    sched off      TOR_HOT_FRAC=0 TOR_PRIO_SHIFT=0                             (no arbiter priorities)
     handoff off    TOR_MIGRATE=0                                               (round-2 behaviour: split mode / wave kernel)
     all off        both
 
@@ -23,9 +23,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 tor = importlib.import_module("trace-of-radiance_amd")
-KNOBS = ("TOR_BACK_SLOT", "TOR_HOT_FRAC", "TOR_PRIO_SHIFT", "TOR_MIGRATE")
-SETTINGS = [("default", {}), ("sched off", {"TOR_BACK_SLOT": "0", "TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0"}), ("handoff off", {"TOR_MIGRATE": "0"}),
-            ("all off", {"TOR_BACK_SLOT": "0", "TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0", "TOR_MIGRATE": "0"})]
+KNOBS = ("TOR_HOT_FRAC", "TOR_PRIO_SHIFT", "TOR_MIGRATE")
+SETTINGS = [("default", {}), ("sched off", {"TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0"}), ("handoff off", {"TOR_MIGRATE": "0"}),
+            ("all off", {"TOR_HOT_FRAC": "0", "TOR_PRIO_SHIFT": "0", "TOR_MIGRATE": "0"})]
 
 
 def multi_group_scene():

@@ -48,15 +48,13 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const unsigned* pixel_cos
 
 // Counting sort of the tiles by descending key (longest-processing-time-first: a pixel is a sequential chain of spp
 // samples, so the long chains must start at t = 0).  One workgroup; the order of equal-key tiles is irrelevant (the
-// schedule never changes a pixel's value).  Two cuts of the sorted list, both by probed work:
+// schedule never changes a pixel's value).  One cut of the sorted list, by probed work:
 //  * split_frac > 0: the first K tiles carry split_frac of the work (the longest chains: they go to coop_pixel_kernel,
 //    one wave per pixel); the lane kernel's counter is started at tile K, K is written for the wave kernel to read;
-//  * tail_frac: the last tiles, carrying tail_frac of the lane kernel's work, form region B of the lane kernel's
-//    schedule: sched[0] = first index of B, sched[1] = B's work counter (started there);
-//  * sched[2] = hot_chain x the probed total: the chain length (bounce iterations) from which a pixel is HOT (priority 3).
+//  * sched[0] = hot_chain x the probed total: the chain length (bounce iterations) from which a pixel is HOT (priority 3).
 __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* ghist, const unsigned long long* gwork, unsigned* goffs, int n_tiles,
                                                           float split_frac, unsigned long long* split_out,
-                                                          unsigned long long* lane_counter, float tail_frac, float hot_chain,
+                                                          unsigned long long* lane_counter, float hot_chain,
                                                           unsigned long long* sched, const MigSchedule mig) {
   // (one workgroup, but only over the 4096 bins: the per-tile passes on either side -- histogram in tile_key_kernel, placement
   // in tile_scatter_kernel -- run on the whole machine; round 2 did all three here in 0.49 ms at 1080p)
@@ -88,28 +86,14 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* ghist,
       return k;
     };
     unsigned k_split = 0;
-    unsigned long long lane_work = total;
     if (split_out != nullptr) {
       const unsigned long long target = (unsigned long long)((double)split_frac * (double)total);
       k_split = tiles_for(target);
       *split_out = k_split;
       *lane_counter = (unsigned long long)k_split * kTilePixels;
-      lane_work = total > target ? total - target : 0;
     }
-    if (sched != nullptr) {
-      const unsigned long long front = total - (unsigned long long)((double)tail_frac * (double)lane_work);
-      unsigned k_tail = tiles_for(front);
-      if (k_tail > (unsigned)n_tiles) k_tail = (unsigned)n_tiles;
-      // Region A must not be empty: a slow-slot wave takes from B only while the front waves are still inside A, and with
-      // an empty A (tail_frac >= 1, or a split that takes all of it) no wave would ever fetch B when every wave of the
-      // launch sits in a slow slot -- tiles never rendered.  Then there is no region B: everything is A, and the
-      // slow-slot waves turn into front waves at their first fetch (integrate_kernel: "B ran dry").
-      if (k_tail <= k_split) k_tail = (unsigned)n_tiles;
-      sched[0] = (unsigned long long)k_tail * kTilePixels;
-      sched[1] = (unsigned long long)k_tail * kTilePixels;
-      // hot chains: hot_chain x the probed total, scaled by the host to bounce iterations of the frame
-      sched[2] = hot_chain > 0.0f ? (unsigned long long)(hot_chain * (float)total) + 1ull : 0ull;
-    }
+    // hot chains: hot_chain x the probed total, scaled by the host to bounce iterations of the frame
+    if (sched != nullptr) sched[0] = hot_chain > 0.0f ? (unsigned long long)(hot_chain * (float)total) + 1ull : 0ull;
     if (mig.mig != nullptr) {
       // Chain hand-off (integrate_kernel / serve_chains).  l_avg = bounce iterations an average lane runs in this frame.
       // The longest chains (glass: ~34 queries per sample whatever the frame) are a fixed number of iterations, so the

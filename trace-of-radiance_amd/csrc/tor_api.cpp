@@ -339,15 +339,9 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* w = tor::knob("TOR_WAVES_PER_SIMD")) ctx->waves_override = std::atoi(w);
   if (const char* l = tor::knob("TOR_LPT_MIN_SPP")) ctx->lpt_min_spp = std::atoi(l);
   if (const char* c = tor::knob("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
-  if (const char* c = tor::knob("TOR_BACK_SLOT")) ctx->back_slot = std::atoi(c);
-  if (const char* c = tor::knob("TOR_BACK_ACCEL")) ctx->back_accel = std::atoi(c) != 0;
-  if (const char* c = tor::knob("TOR_PROBE_SPP")) ctx->probe_spp = std::atoi(c) > 0 ? std::atoi(c) : 2;
   if (const char* c = tor::knob("TOR_HOT_FRAC")) ctx->hot_frac = (float)std::atof(c);
-  if (const char* c = tor::knob("TOR_TAIL_FRAC")) ctx->tail_frac = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_PRIO_SHIFT")) ctx->prio_shift = std::atoi(c);
   if (const char* c = tor::knob("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
-  if (const char* c = tor::knob("TOR_SPLIT_MIN_PIXELS")) ctx->split_min_pixels = std::atoll(c);
-  if (const char* c = tor::knob("TOR_SPLIT_MAX_PIXELS")) ctx->split_max_pixels = std::atoll(c);
   if (const char* c = tor::knob("TOR_MIGRATE")) ctx->mig_mode = std::atoi(c);
   if (const char* c = tor::knob("TOR_SRV_FRAC")) ctx->srv_frac = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_SRV_PATIENCE_US")) ctx->srv_patience_us = std::atoi(c);
@@ -356,10 +350,8 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = tor::knob("TOR_FLOOR_THETA")) ctx->floor_theta = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_CHAIN_THETA")) ctx->chain_theta = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_TAIL_LANES")) ctx->mig_tail_lanes = std::atoi(c);
-  if (const char* c = tor::knob("TOR_PROBE_ACCEL")) ctx->probe_accel = std::atoi(c) != 0;
   if (const char* c = tor::knob("TOR_SCREEN")) ctx->screen = std::atoi(c) != 0;
   if (const char* c = tor::knob("TOR_PLANE")) ctx->plane_screen = std::atoi(c);  // 0 off, 1 gated (default), 2 on every segment that carries the table
-  if (const char* c = tor::knob("TOR_KEY_MODE")) ctx->key_mode = std::atoi(c);
   if (const char* c = tor::knob("TOR_TAIL_REST")) ctx->mig_tail_rest = std::atoi(c);
   if (const char* c = tor::knob("TOR_MIG_FLAGS")) ctx->mig_flags = (unsigned)std::strtoul(c, nullptr, 0);
   if (const char* b = tor::knob("TOR_BLOCKS_PER_CU"))
@@ -869,14 +861,9 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       split = tor::coop_blocks_per_cu(wk, o.arith) > 0;
     }
     unsigned* const tile_key = (unsigned*)tile_cost.ptr + npix;
-    // schedule of the lane kernel (tor_kernels.hip): two regions where some wave slot is slow enough to need it, and the
-    // hot chains: a pixel chain is hot when it needs more than hot_frac of the iterations an average wave runs in this frame
+    // schedule of the lane kernel (tor_kernels.hip): the hot chains -- a pixel chain is hot when it needs more than hot_frac of the
+    // iterations an average wave runs in this frame
     //   average = total probed queries * spp / probe_spp / lanes
-    // (TOR_BACK_SLOT=-1, a test setting: EVERY wave is treated as a slow-slot wave -- what a launch sees when other
-    // kernels hold the fast slots of the device)
-    const bool two_regions = (ctx->back_slot == -1 || (ctx->back_slot > 0 && ctx->back_slot < waves_per_simd)) && ctx->tail_frac > 0.0f &&
-                             (o.accel == 0 || ctx->back_accel);
-    p.back_slot = two_regions ? (ctx->back_slot == -1 ? 0 : ctx->back_slot) : 1 << 20;
     p.prio_shift = ctx->prio_shift;
     p.sched = slot_counters + 8;
     tor::MigSchedule ms;
@@ -914,7 +901,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     }
     HIP_TRY(tor::launch_tile_order((const unsigned*)tile_cost.ptr, (unsigned)npix, tile_key, tile_key + n_tiles, (unsigned*)tile_order.ptr,
                                    (int)n_tiles, split ? split_frac : 0.0f, split ? slot_counters + 6 : nullptr,
-                                   split ? slot_counters : nullptr, two_regions ? ctx->tail_frac : 0.0f,
+                                   split ? slot_counters : nullptr,
                                    ctx->hot_frac > 0.0f ? ctx->hot_frac * (float)spp / (float)ctx->probe_spp / (float)(resident_waves * 64) : -1.0f,
                                    p.sched, ms, stream));
     p.order = (const unsigned*)tile_order.ptr;

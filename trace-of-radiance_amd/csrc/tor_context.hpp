@@ -120,16 +120,9 @@ struct TorContext {
   tor::DeviceBuffer counters;                      // kRing x 8 u64: [0] work counter, [1..4] stats, [5] probe counter
   tor::DeviceBuffer tile_order[kRing];  // SEED_PIXEL schedule: the tile order a launch reads
   tor::DeviceBuffer probe_buf;          // ... and what the sort is made from: per-pixel probe counts, per-tile key and work
-  // SEED_PIXEL: wave slots >= this take tiles from the cheap end (0 = none; TOR_BACK_SLOT).  Round 4: 0.  The two-region schedule
-  // was worth 5-10 % to the float64 brute force of rounds 2-3 (slot 2 of a SIMD got a fifth of slot 0's service); with the round-4
-  // object loop it COSTS 4-7 % (profiles/r4_pixel_brute_knobs.txt: 1777 -> 1851 Msamples/s at configs[2], 1677 -> 1795 at
-  // configs[1] with it off; the cost-ordered tile list itself stays essential: 1059 without it).
-  int back_slot = 0;
   float hot_frac = 0.4f;   // a pixel chain is hot (arbiter priority 3) from this share of an average wave's iterations on (TOR_HOT_FRAC; 0 = off)
-  float tail_frac = 0.2f;  // share of the lane kernel's probed work in region B of its schedule (TOR_TAIL_FRAC)
-  int probe_spp = 2;            // samples per pixel of the cost probe (TOR_PROBE_SPP: debugging the schedule)
+  int probe_spp = 2;            // samples per pixel of the cost probe
   int64_t last_probe_pixels = 0;
-  bool back_accel = false;  // two regions with an exact acceleration too (TOR_BACK_ACCEL; measured slower: the slots differ less there)
   int prio_shift = 16;  // SEED_PIXEL: arbiter-priority rotation period, log2 shader-clock ticks (tor_kernels.hip; 0 = off; TOR_PRIO_SHIFT)
   tor::DeviceBuffer wave_log;                      // debug: 8 x u64 per wave (only with stats enabled)
   tor::DeviceBuffer cam_ring;                      // kRing x TorCamera
@@ -138,7 +131,7 @@ struct TorContext {
   std::vector<float> bnd32_host[kRing];
   std::vector<double> probe_bnd_host[kRing];  // block bounds of the cost probe when it runs with other accel bits than the frame (host staging of an
   std::vector<float> probe_bnd32_host[kRing];  // asynchronous copy, per ring slot like bnd_host)
-  bool probe_accel = true;  // TOR_PROBE_ACCEL=0: the probe walks the same layout as the frame's kernel
+  bool probe_accel = true;  // the cost probe always walks the culling layout when the scene has one (it only counts queries); (round 5: the TOR_PROBE_ACCEL switch is gone)
   int plane_screen = 1;  // TOR_PLANE: 0 = the wave-uniform test for every object (no plane screen in front), 1 = stage one where it pays (tor_screen.hpp plane_pays), 2 = on every segment with a table
   bool screen = true;       // TOR_SCREEN=0: strict brute-force launches evaluate the reference's unfused discriminant for every object (no FMA screen)
   hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
@@ -190,7 +183,7 @@ struct TorContext {
   int mig_mode = 1;
   float srv_frac = 0.07f, srv_min_frac = 0.005f, push_theta = 3.0f, chain_theta = 3.5f, floor_theta = 1.33f;
   int srv_patience_us = 8000;
-  int key_mode = 1;  // tile sort key of the SEED_PIXEL schedule (TOR_KEY_MODE; tor_kernels.hip tile_key_kernel)
+  int key_mode = 1;  // tile sort key of the SEED_PIXEL schedule: certain long chains first, then by the tile's sum (tile_key_kernel; the round-2 key, 0, is kept for the record only)
   int mig_tail_lanes = 8;
   int mig_tail_rest = 256;   // TOR_TAIL_REST
   unsigned mig_flags = (8u << 8) | 2u | 4u;  // TOR_MIG_FLAGS (tor_kernels.hpp KParams::mig_flags)

@@ -305,12 +305,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned next_chunk = p.chunk;
   const unsigned prio_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_ID.wave_id: the wave's slot in its SIMD
   unsigned prio_now = 0;
-  // SEED_PIXEL tile schedule (see the fetch below): waves of the slow slots skip region A
-  bool from_back = SEEDING == 0 && p.sched != nullptr && prio_slot >= (unsigned)p.back_slot;
-  const unsigned long long a_end = (SEEDING == 0 && p.sched != nullptr) ? p.sched[0] : p.total_work;
   // a pixel chain is HOT when, extrapolated from its samples so far, it needs more than hot_iters bounce iterations
-  const unsigned hot_iters = (SEEDING == 0 && p.sched != nullptr) ? (unsigned)p.sched[2] : 0u;
-  bool a_done = from_back;
+  const unsigned hot_iters = (SEEDING == 0 && p.sched != nullptr) ? (unsigned)p.sched[0] : 0u;
   unsigned pix_iters = 0;  // bounce iterations the lane has spent on its current pixel
   // arbiter priorities (below): every SEED_PIXEL variant.  (In the cooperative variants the lane's iteration counter was
   // one register too many while the pixel sum still lived in registers: 1-2 % slower then, 1-2 % faster at 100 spp now.)
@@ -375,23 +371,18 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       //     a mean of 2.6) that even an average slot would finish it after everybody else.  Judged on the lane's own
       //     record: iterations so far, extrapolated to spp samples, against hot_iters (a share of what an average wave
       //     runs in the whole frame, from the probe's total); a few dozen pixels per frame;
-      //  1-2 fast slots, taking turns (level = 1 + (slot + clock phase) mod 2, the phase from the shader clock they
-      //     share) so that both get the same service;
-      //  0  slow slots (region B only).
+      //  1-2 everybody else, taking turns (level = 1 + (slot + clock phase) mod 2, the phase from the shader clock the slots of
+      //     a SIMD share) so that they get the same service.
       if (active) pix_iters += 1;
       const bool lane_hot = active && hot_iters != 0 && pix_iters >= 64u &&
                             (unsigned long long)pix_iters * (unsigned)p.spp >= (unsigned long long)hot_iters * (unsigned)(s + 1);
       const bool wave_hot = ballot64(lane_hot) != 0;
-      unsigned level = 0;
-      if (wave_hot || (from_back && exhausted)) {
+      unsigned level = 1;
+      if (wave_hot) {
         level = 3;
-      } else if (!from_back) {
-        level = 1;
-        if (p.prio_shift > 0) {
-          const unsigned n_front = ((unsigned)p.back_slot < (unsigned)WAVES_PER_SIMD) ? (unsigned)p.back_slot : (unsigned)WAVES_PER_SIMD;
-          const unsigned phase = (unsigned)(__builtin_readcyclecounter() >> p.prio_shift);
-          level = 1u + (prio_slot + phase) % (n_front < 2u ? 1u : 2u);
-        }
+      } else if (p.prio_shift > 0) {
+        const unsigned phase = (unsigned)(__builtin_readcyclecounter() >> p.prio_shift);
+        level = 1u + (prio_slot + phase) % (WAVES_PER_SIMD < 2 ? 1u : 2u);
       }
       // (s_setprio is a scalar instruction: it must sit behind scalar branches.  Everything `level` depends on is the same
       // in all lanes, but some of it is assigned under conditions the compiler cannot prove uniform; as a vector value the
@@ -743,7 +734,7 @@ hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
 }
 
 hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
-                             float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
+                             float split_frac, unsigned long long* split_out, unsigned long long* lane_counter,
                              float hot_chain, unsigned long long* sched, const MigSchedule& mig, hipStream_t stream) {
   // sort scratch behind the per-tile arrays (tor_api.cpp sizes the buffer): histogram (tiles, work per key), running offsets
   unsigned long long* gwork = (unsigned long long*)(((uintptr_t)(work + n_tiles) + 7) & ~(uintptr_t)7);
@@ -754,7 +745,7 @@ hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsi
   hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, pixel_cost, n_pixels, n_tiles, key, work,
                      (unsigned)mig.key_mode, (unsigned)(mig.probe_spp > 0 ? mig.probe_spp : 2), ghist, gwork);
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned*)ghist, (const unsigned long long*)gwork, goffs, n_tiles,
-                     split_frac, split_out, lane_counter, tail_frac, hot_chain, sched, mig);
+                     split_frac, split_out, lane_counter, hot_chain, sched, mig);
   hipLaunchKernelGGL(tile_scatter_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, (const unsigned*)key, goffs, order, n_tiles);
   return hipGetLastError();
 }

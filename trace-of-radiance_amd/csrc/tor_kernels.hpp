@@ -76,8 +76,7 @@ struct KParams {
   unsigned n_pixels;  // local pixels (rows of this shard x ncols)
   const unsigned* order;  // SEED_PIXEL: nullable tile order (cost-descending), n_tiles entries
   unsigned* pixel_cost;   // probe launch: per-pixel closest-hit query count (2 samples)
-  unsigned long long* sched;  // SEED_PIXEL + order: [0] first index of region B of the order, [1] region B's work counter, [2] hot chain length; else null
-  int back_slot;          // SEED_PIXEL: waves in hardware wave slots >= back_slot take tiles from region B only
+  unsigned long long* sched;  // SEED_PIXEL + order: [0] hot chain length (bounce iterations from which a pixel chain gets arbiter priority 3); else null
   int prio_shift;         // SEED_PIXEL: rotate the waves' arbiter priority every 2^prio_shift shader-clock ticks (0 = off)
   unsigned long long total_work;
   unsigned long long* work_counter;
@@ -150,7 +149,7 @@ struct MigSchedule {
   int key_mode = 0, probe_spp = 2;  // tile sort key (tile_key_kernel): 0 = longest probed pixel, 1 = certain long chains first, then by the tile's sum
 };
 hipError_t launch_tile_order(const unsigned* pixel_cost, unsigned n_pixels, unsigned* key, unsigned* work, unsigned* order, int n_tiles,
-                             float split_frac, unsigned long long* split_out, unsigned long long* lane_counter, float tail_frac,
+                             float split_frac, unsigned long long* split_out, unsigned long long* lane_counter,
                              float hot_chain, unsigned long long* sched, const MigSchedule& mig, hipStream_t stream);
 bool integrate_variant_serves_chains(const KParams& p, int seeding);  // the launch's kernel variant carries the server code
 constexpr int kTilePixelsHost = 64;  // == kTilePixels in tor_kernels.hip

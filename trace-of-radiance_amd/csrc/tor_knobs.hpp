@@ -31,29 +31,18 @@ constexpr Knob kKnobs[] = {
     {"TOR_RCCL_TIMEOUT_MS", "10000 + 1 per MB", "> 0", "call", "deadline of one RCCL framebuffer transfer; past it the communicators are aborted and TOR_GATHER=auto carries on with peer copies"},
     {"TOR_RCCL_INIT_TIMEOUT_MS", "120000", "> 0", "call", "deadline of communicator creation + self-check (runs in a helper thread that is abandoned when it does not return)"},
     {"TOR_FAULT_INJECT", "(none)", "comma list of rccl_init | rccl_xfer | rccl_hang | peer", "call", "TEST: the named gather leg fails (or, rccl_hang, never completes) at that point"},
-    {"TOR_COPY_CHUNK_KB", "2048", "> 0", "call", "chunk size of the pinned D2H staging of a host canvas"},
-    {"TOR_COPY_THREADS", "8", ">= 1", "call", "host threads that move staged chunks into the caller's canvas"},
     // ---- launch shape ----
     {"TOR_BLOCKS_PER_CU", "3", "1..8", "context", "workgroups per CU of integrate_kernel (all modes)"},
     {"TOR_WAVES_PER_SIMD", "(from the launch shape)", "2 | 3", "context", "force the register-budget variant of integrate_kernel (256 / 168 VGPRs)"},
     {"TOR_STAGE_LDS", "(no cap)", "bytes, 0 = off", "call", "cap of the LDS staging of block records / boxes (TOR_ACCEL_BLOCKS)"},
     {"TOR_SCREEN", "1", "0 | 1", "context", "0: strict brute-force launches evaluate the reference's unfused discriminant for every object instead of the conservative FMA screen (same canvas)"},
     {"TOR_PLANE", "1", "0 | 1 | 2", "context", "stage one of the FMA screen (the 4-instruction plane screen in front of the segment's wave-uniform test, per-lane stage two on what it keeps): 0 off, 1 on the segments where it pays (default), 2 on every segment (same candidates, same canvas)"},
-    {"TOR_TWO_LEVEL_MIN", "96", "blocks", "upload", "culling layouts with MORE than this many boxes get super boxes (two-level)"},
     // ---- TOR_SEED_PIXEL: kernel choice, cost probe, tile schedule ----
     {"TOR_COOP_MAX_PIXELS", "114688", ">= 0", "context", "frames up to this many pixels (per device) run one WAVE per pixel when neither hand-off nor split mode applies; 0 = never"},
     {"TOR_LPT_MIN_SPP", "32", ">= 0", "context", "cost probe + chain-length-ordered tile schedule from this many spp on; 0 = never"},
-    {"TOR_PROBE_SPP", "2", ">= 1", "context", "samples per pixel of the cost probe"},
-    {"TOR_PROBE_ACCEL", "1", "0 | 1", "context", "1: the probe always walks the culling layout (it only counts queries); 0: the frame's layout"},
-    {"TOR_KEY_MODE", "1", "0 | 1", "context", "tile sort key: 0 longest probed pixel, 1 certain long chains first, then the tile's sum"},
-    {"TOR_BACK_SLOT", "0", "-1 | 0..", "context", "two-region tile schedule of the brute force: waves in hardware slots >= this take tiles from the cheap end only; 0 = none (default since round 4: it costs the new object loop 4-7 %), 2 = rounds 2-3, -1 = every wave (test setting)"},
-    {"TOR_BACK_ACCEL", "0", "0 | 1", "context", "two schedule regions with an exact acceleration too"},
-    {"TOR_TAIL_FRAC", "0.2", "0..1", "context", "share of the probed work in region B of the schedule"},
     {"TOR_HOT_FRAC", "0.4", ">= 0", "context", "a pixel chain is HOT (arbiter priority 3) from this share of an average wave's iterations; 0 = off"},
     {"TOR_PRIO_SHIFT", "16", "0..31", "context", "arbiter-priority rotation period, log2 shader-clock ticks; 0 = off"},
     {"TOR_SPLIT_FRAC", "(automatic)", "0..1", "context", "split mode: share of the probed cost that goes to the wave-per-pixel kernel; 0 = off"},
-    {"TOR_SPLIT_MIN_PIXELS", "16384", ">= 0", "context", "split mode from this many pixels"},
-    {"TOR_SPLIT_MAX_PIXELS", "100000000", ">= 0", "context", "split mode up to this many pixels"},
     // ---- TOR_SEED_PIXEL chain hand-off ----
     {"TOR_MIGRATE", "1", "0 | 1", "context", "0: no chain hand-off (split mode / wave-per-pixel kernel instead)"},
     {"TOR_SRV_FRAC", "0.07", "0..1", "context", "share of the workgroups that start as servers when the frame can hold a chain above the threshold's floor"},

@@ -118,7 +118,6 @@ int download_rows(TorContext* ctx, const void* d_src, int64_t n_rows, size_t row
   const size_t total = (size_t)n_rows * row_bytes;
   HIP_TRY(ctx->staging.ensure(total));
   size_t chunk_target = (size_t)2 << 20;  // measured on C2 (tools/host_canvas_tune.py): 8 threads x 2 MiB
-  if (const char* e = tor::knob("TOR_COPY_CHUNK_KB")) chunk_target = (size_t)std::atoll(e) << 10;
   int64_t rows_per_chunk = (int64_t)(chunk_target / row_bytes);
   if (rows_per_chunk < 1) rows_per_chunk = 1;
   const int64_t n_chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
@@ -135,7 +134,6 @@ int download_rows(TorContext* ctx, const void* d_src, int64_t n_rows, size_t row
     HIP_TRY(hipEventRecord(ctx->chunk_events[(size_t)c], stream));
   }
   int n_workers = 8;
-  if (const char* e = tor::knob("TOR_COPY_THREADS")) n_workers = std::atoi(e);
   if (n_workers < 1) n_workers = 1;
   if (n_workers > n_chunks) n_workers = (int)n_chunks;
   std::atomic<int> first_error{(int)hipSuccess};

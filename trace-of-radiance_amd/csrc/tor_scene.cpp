@@ -632,7 +632,6 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   const size_t n_super = n_bnd_p / kPad;
   const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;
   size_t two_level_min = 96;
-  if (const char* e = tor::knob("TOR_TWO_LEVEL_MIN")) two_level_min = (size_t)std::atoll(e);
   out.two_level = out.n_boxes > two_level_min;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
   if (out.two_level)
     out.always.segs.insert(out.always.segs.end(), {4.0, (double)(n_bnd_p + 1), (double)n_super_p, 0.0, 0.0, 0.0, 0.0, 0.0});
