@@ -28,9 +28,16 @@ namespace tor {
 //                   disc' >= (H - mu)^2 - a C + a M - 48 u B^2 a > (256 - 19 - 48) u B^2 a > 0.
 // Nothing the reference accepts is dropped.  Overflowing margins (|o| beyond 1e150) keep everything; a NaN is dropped
 // by both tests or re-tested exactly; a = 0 (d = 0) keeps everything and the exact test rejects it (disc = 0).
+// (TOR_SCREEN_MUTATE: the mutation check of tools/mutation_check.sh -- every margin of the three screens set to zero; the host
+// tests of tests/test_screen.py must then FAIL, which shows that they sit on the decision boundary.  Never defined in a product build.)
+#if defined(TOR_SCREEN_MUTATE) && TOR_SCREEN_MUTATE == 1
+#define TOR_MARGIN(x) 0.0
+#else
+#define TOR_MARGIN(x) (x)
+#endif
 TOR_HD void screen_margins(double B, double d1, double a, double& negmu, double& am) {
-  negmu = -(B * d1) * 0x1p-48;
-  am = a * ((B * B) * 0x1p-45);
+  negmu = TOR_MARGIN(-(B * d1) * 0x1p-48);
+  am = TOR_MARGIN(a * ((B * B) * 0x1p-45));
 }
 // returns a word whose SIGN BIT is the decision (set = keep)
 TOR_HD int screen_filter(double ocx, double ocy, double ocz, double dx, double dy, double dz, double a, double negmu,
@@ -144,9 +151,9 @@ TOR_HD double fma_clamp_v(double a, double b, double c) {
 TOR_HD ScreenSeg screen2_seg(const ScreenRay& r, double reach, double travel, double y_rel, double f) {
   ScreenSeg s;
   const double B = r.s1 + reach + travel * __builtin_fabs(f);
-  const double mu = B * 0x1p-47;
-  const double M = (B * B) * 0x1p-45;
-  const bool wild = r.wild || !(M < __builtin_inf());
+  const double mu = TOR_MARGIN(B * 0x1p-47);
+  const double M = TOR_MARGIN((B * B) * 0x1p-45);
+  const bool wild = r.wild || !((B * B) * 0x1p-45 < __builtin_inf());
   // sigma = 2^-(e + 2) for B in [2^e, 2^(e+1)): sigma B < 1/2.  (B = 0 or denormal: 2^1020; harmless, every product below is 0 or tiny)
   uint64_t e = (double_to_bits(B) >> 52) & 0x7ffu;
   if (e < 3u) e = 3u;
@@ -266,8 +273,13 @@ TOR_HD PlaneRay plane_ray(const ScreenRay& r) {
 TOR_HD PlaneSeg plane_seg(const ScreenRay& r, const PlaneRay& pr, double reach, double travel, double f, double rmax2) {
   PlaneSeg s;
   const double B = r.s1 + reach + travel * __builtin_fabs(f);
+#if defined(TOR_SCREEN_MUTATE)   // (level 2 of the mutation check: only stage one's margins)
+  const double M = 0.0;
+  const double thr = rmax2 * pr.w2;
+#else
   const double M = (B * B) * 0x1p-45;
   const double thr = (fma_(rmax2, 0x1p-40, rmax2) + M) * pr.w2;
+#endif
   const bool all = pr.all || !(thr >= 0x1p-900 && thr < __builtin_inf());
   s.nx = all ? 0.0 : pr.nx;
   s.nz = all ? 0.0 : pr.nz;
