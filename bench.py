@@ -153,7 +153,7 @@ def pmc_child(spec):
     cv = tor.new_canvas(H, W, spp, 2.2)
     # two identical calls; live_traffic() reads the counters of the SECOND launch -- the steady state every timed step of the
     # host-canvas leg is in.  The first launch of a process (fresh allocations) fetches the canvas once from HBM and writes it
-    # back as 64-byte lines on top: +65 MB read, +123 MB written at 1080p (profiles/r3_traffic_reconcile.txt)
+    # back as 64-byte lines on top: +65 MB read, +123 MB written at 1080p (profiles/r3_traffic_reconcile.txt, HISTORY 6)
     for _ in range(2):
         tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, arith=arith, accel=accel, shard_index=shard_index,
                                                                   shard_count=shard_count, row_tile=row_tile))

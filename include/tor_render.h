@@ -166,7 +166,7 @@ typedef struct TorOptions {
   /* TOR_SEED_PIXEL only: which kernel walks the pixel chains (same canvas either way).
    * TOR_PIXEL_KERNEL_AUTO: with both exact accelerations, >= 32 spp and a single-level culling layout (<= 128 block
    * boxes) every frame size runs the one-lane-per-pixel kernel with the CHAIN HAND-OFF -- lanes push their long pixel
-   * chains to server waves inside the same launch (the launch covers the whole GPU and assumes exclusive
+   * chains to server waves inside the same launch (DESIGN 4.7 (HISTORY 4.7-4.8); the launch covers the whole GPU and assumes exclusive
    * use of it: tor_context_handoff_stalled; TOR_MIGRATE=0 turns it off).  Where the hand-off cannot run: frames of
    * 16 K pixels and more (per device) with both accelerations and >= 32 spp are SHARED -- the tiles that carry the
    * largest part of a probed cost go to the one-wave-per-pixel kernel on a second stream, the lane kernel renders the
@@ -303,7 +303,7 @@ TOR_API int tor_render_gather_device(TorContext* ctx, const TorCamera* cam, int3
                                      int32_t samples_per_pixel, float gamma_correction, int64_t max_depth,
                                      const TorOptions* opt, int32_t root, double* d_frame, void* hip_stream);
 
-/* Chain hand-off of the last launch of `ctx` (TOR_SEED_PIXEL with both exact accelerations): the launch covers
+/* Chain hand-off of the last launch of `ctx` (TOR_SEED_PIXEL with both exact accelerations, DESIGN 4.7 (HISTORY 4.7-4.8)): the launch covers
  * the whole GPU and its waves wait for each other, so it assumes exclusive use of the device's compute units (hand-off
  * launches of ONE process are chained per device by the library; TOR_MIGRATE=0 turns the hand-off off).  If some of its
  * workgroups never become resident (another process's persistent kernel, a CU mask) the waiting waves give up after

@@ -1,5 +1,5 @@
 """GPU tests added in round 3:
- * the SEED_PIXEL chain hand-off: lanes push long pixel chains to server waves inside the same launch --
+ * the SEED_PIXEL chain hand-off (DESIGN 4.7 (HISTORY 4.10)): lanes push long pixel chains to server waves inside the same launch --
    same canvas bit for bit under every setting of its knobs, == oracle, == the reference PNG at C1;
  * the multi-GPU path's fallback chain (TOR_FAULT_INJECT), still on one GPU;
  * ABI nits: tor_last_render_timing measured with events, the one-stream-per-context rule, option validation;

@@ -1,7 +1,10 @@
 """Differential fuzz of the exact accelerations on the GPU: random scenes and cameras, every accel mode -- and the brute force
-WITHOUT its conservative FMA screen (TOR_SCREEN=0, DESIGN 4.11: no plane screen, no second form, the reference's unfused
-discriminant for every object) -- against the float64 brute-force canvas, bit for bit.
-Usage: python tools/fuzz_accel.py [seconds] [seed]"""
+WITHOUT its conservative FMA screen (TOR_SCREEN=0, DESIGN 4.2: no plane screen, no second form, the reference's unfused
+discriminant for every object) and the brute force with stage one of the screen FORCED onto every segment that carries a plane
+table (TOR_PLANE=2: no gate) -- against the float64 brute-force canvas (default: the host's gate and the waves' votes decide per
+segment), bit for bit.
+Usage: python tools/fuzz_accel.py [seconds] [seed] [heights]     heights: mixed (default: half of the scenes rest their spheres on
+1-4 common heights) | none (every sphere at its own height: no common-height segment anywhere -- the round-5 record)"""
 import importlib
 import os
 import sys
@@ -14,21 +17,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tor = importlib.import_module("trace-of-radiance_amd")
 
 
+HEIGHTS = "mixed"
+
+
 def random_scene(rng):
     n = int(rng.choice([40, 90, 200, 485, 700, 1300]))
     spread = float(rng.choice([0.02, 1.0, 4.0, 12.0, 60.0, 3000.0]))
     shift = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 10.0, 1e3, 1e5]))
     rscale = spread / 12.0
-    groups = [(0.0, 1.0), (-0.5, 0.5), (0.25, 2.0), (1.0, 0.0)][: int(rng.integers(1, 5))]
+    groups = [(0.0, 1.0), (-0.5, 0.5), (0.25, 2.0), (1.0, 0.0), (0.5, 0.5)][: int(rng.integers(1, 6))]   # (the last: time0 == time1, never a finite fraction)
     recs = []
     if rng.random() < 0.6:
         R = float(rng.choice([100.0, 1000.0])) * rscale
         recs.append([0, shift[0], shift[1] - R, shift[2], shift[0], shift[1] - R, shift[2], 0, 1, R, 0, .5, .5, .5, 0, 0])
     mover_frac = float(rng.choice([0.0, 0.5, 0.9]))
     general = rng.random() < 0.4
+    per_object = rng.random() < 0.3     # movers along y and movers in general position in ONE scene (and in one time group)
     # spheres resting at a few common heights (bit-identical c0.y: the strict loop's common-height segments and the plane screen in
-    # front of them, DESIGN 4.12 / 4.14) in half of the scenes; any height in the others
-    levels = shift[1] + rng.uniform(0, 0.3 * spread, int(rng.integers(1, 5))) if rng.random() < 0.5 else None
+    # front of them, DESIGN 4.2) in half of the scenes; any height in the others
+    levels = shift[1] + rng.uniform(0, 0.3 * spread, int(rng.integers(1, 5))) if (HEIGHTS == "mixed" and rng.random() < 0.5) else None
     while len(recs) < n:
         c = shift + np.array([rng.uniform(-spread, spread), rng.uniform(0, 0.3 * spread), rng.uniform(-spread, spread)])
         if levels is not None and rng.random() < 0.9:
@@ -41,7 +48,8 @@ def random_scene(rng):
             recs.append([0, *c, *c, 0, 1, r, mat, *alb, fuzz, ri])
         else:
             t0, t1 = groups[int(rng.integers(0, len(groups)))]
-            d = rng.uniform(-0.6, 0.6, 3) * rscale if general else np.array([0.0, rng.uniform(0, 0.6) * rscale, 0.0])
+            g = (rng.random() < 0.5) if per_object else general
+            d = rng.uniform(-0.6, 0.6, 3) * rscale if g else np.array([0.0, rng.uniform(0, 0.6) * rscale, 0.0])
             recs.append([1, *c, *(c + d), t0, t1, r, mat, *alb, fuzz, ri])
     recs = np.asarray(recs, dtype=np.float64)
     inside = rng.random() < 0.3
@@ -57,9 +65,14 @@ def random_scene(rng):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    global HEIGHTS
+    HEIGHTS = sys.argv[3] if len(sys.argv) > 3 else "mixed"
     os.environ["TOR_SCREEN"] = "0"
     unscreened = tor.Context(0)      # (the knob is read when a context is made; tor.render() below uses the default context)
     os.environ.pop("TOR_SCREEN", None)
+    os.environ["TOR_PLANE"] = "2"
+    forced = tor.Context(0)
+    os.environ.pop("TOR_PLANE", None)
     t0 = time.time()
     n_scenes = n_renders = bad = 0
     while time.time() - t0 < budget:
@@ -86,6 +99,14 @@ def main():
             if not np.array_equal(canv[0], plain, equal_nan=True):
                 bad += 1
                 print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} TOR_SCREEN=0: {int((canv[0] != plain).sum())} values differ", flush=True)
+            forced.upload(scene.list())
+            forced.render_device(cam, h, w, spp, 2.2, depth, tor.make_options(seeding=seeding, accel=0, pixel_kernel=1), buf.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            n_renders += 1
+            if not np.array_equal(canv[0], buf.cpu().numpy(), equal_nan=True):
+                bad += 1
+                print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} TOR_PLANE=2: {int((canv[0] != buf.cpu().numpy()).sum())} values differ", flush=True)
             if seeding == 0:  # the wave-per-pixel kernel (TorOptions.pixel_kernel = 2) against the lane kernel's brute force
                 cv = tor.new_canvas(h, w, spp, 2.2)
                 tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=0, accel=0, pixel_kernel=2))
@@ -99,7 +120,7 @@ def main():
                     print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} accel {accel}: "
                           f"{int((canv[0] != canv[accel]).sum())} values differ", flush=True)
         n_scenes += 1
-    print(f"fuzz: {n_scenes} scenes, {n_renders} renders, {bad} mismatches in {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz (heights: {HEIGHTS}): {n_scenes} scenes, {n_renders} renders, {bad} mismatches in {time.time() - t0:.0f} s", flush=True)
     sys.exit(1 if bad else 0)
 
 

@@ -1,4 +1,4 @@
-"""Chain hand-off on vs off: same canvas, step time, hand-off counters.
+"""Chain hand-off (DESIGN 4.7 (HISTORY 4.10)) on vs off: same canvas, step time, hand-off counters.
 usage (GPU box): python tools/mig_check.py [HxWxSPP[:k/N] ...]   (k/N = row shard k of N)"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Is the SEED_PIXEL schedule (chain-ordered tiles, two regions, arbiter priorities) and the chain hand-off
- tuned to ONE scene?  
+"""Is the SEED_PIXEL schedule (DESIGN 4.7 (HISTORY 4.9): chain-ordered tiles, two regions, arbiter priorities) and the chain hand-off
+(DESIGN 4.7 (HISTORY 4.10)) tuned to ONE scene?  
 
 Four workloads -- the bench scene and three others the tests already hold -- x {float64 brute force, tor_render()'s default
 accelerations} x four settings of the scheduling machinery, every canvas compared with the first setting's:

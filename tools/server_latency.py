@@ -1,4 +1,4 @@
-"""Latency of a server's bounce: a frame so small that nearly every wave is idle -- its time is its longest
+"""Latency of a server's bounce (DESIGN 4.7 (HISTORY 4.10)): a frame so small that nearly every wave is idle -- its time is its longest
 pixel chain x the time of one dependent bounce in serve_chains.  Prints kernel ms, the hand-off timeline and, from the
 probe-independent bookkeeping, microseconds per served bounce of the busiest chain.
 usage (GPU box): python tools/server_latency.py [H W spp]"""

@@ -1,4 +1,4 @@
-"""Where does a server's bounce go?  (the floor of a frame with a long pixel chain is chain length x the time of one
+"""Where does a server's bounce go?  (DESIGN 4.7 (HISTORY 4.10): the floor of a frame with a long pixel chain is chain length x the time of one
 dependent bounce in serve_chains.)  Needs the profiling build (make -C trace-of-radiance_amd/csrc prof): shader-clock stamps around
 the phases of every served bounce -- closest-hit query (ray set-up, slab tests, candidate records, float64 tests, wave minimum),
 shading per material, sky, camera ray of a new sample.

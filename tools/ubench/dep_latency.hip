@@ -1,5 +1,5 @@
 // dep_latency.hip -- microbenchmark: how many shader cycles does ONE wave need per instruction of a dependent float64 chain
-// (the server side of the chain hand-off, DESIGN 4.10, is one such chain per bounce), and does a narrower EXEC mask or
+// (the server side of the chain hand-off, DESIGN 4.7 (HISTORY 4.10), is one such chain per bounce), and does a narrower EXEC mask or
 // instruction-level parallelism change it?
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ubench/dep_latency.hip -o /tmp/dep_latency && /tmp/dep_latency
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// mfma_f64_rate.hip -- GATE for "the FMA screen as a contraction on the float64 matrix pipe" (DESIGN 4.12).
+// mfma_f64_rate.hip -- GATE for "the FMA screen as a contraction on the float64 matrix pipe" (DESIGN 4.2).
 // Question: does v_mfma_f64_16x16x4_f64 add float64 throughput ON TOP of the VALU's v_fma_f64 on gfx950, or do the two share
 // one issue / one datapath?  Measured on the whole machine (every SIMD loaded), in wave-instructions and in flop:
 //   A  v_fma_f64 only                       (8 independent chains per lane)

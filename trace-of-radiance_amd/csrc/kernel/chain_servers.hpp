@@ -60,7 +60,7 @@ __device__ __forceinline__ V3 random_unit_vector(SrvRng& g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// serve_chains -- the SERVER side of the SEED_PIXEL chain hand-off, inside integrate_kernel<0, A, W, 1, 1>.
+// serve_chains -- the SERVER side of the SEED_PIXEL chain hand-off (DESIGN 4.7 (HISTORY 4.10)), inside integrate_kernel<0, A, W, 1, 1>.
 //
 // A server is a whole wave that continues ONE pixel chain at a time from the state a lane pushed at a sample boundary
 // (pixel, samples done, xoshiro256+ state, running sum): the same stream, the same operations, the same pixel -- only the

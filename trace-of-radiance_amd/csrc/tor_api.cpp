@@ -685,7 +685,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
     return TOR_OK;
   };
   const long long n_tiles = (npix + tor::kTilePixelsHost - 1) / tor::kTilePixelsHost;
-  // Chain hand-off: the lane kernel pushes its long chains to server waves inside the same launch -- it
+  // Chain hand-off (DESIGN 4.7 (HISTORY 4.10)): the lane kernel pushes its long chains to server waves inside the same launch -- it
   // replaces both the whole-frame wave kernel and split mode wherever the launch's kernel variant carries the servers
   // (both exact accelerations, single-level culling layout with float32 records, <= 128 block boxes) and the probe runs.
   // Decided HERE, in full, before split mode and the wave-per-pixel kernel are ruled out: a frame whose hand-off cannot

@@ -174,7 +174,7 @@ struct TorContext {
   long long split_min_pixels = 16384, split_max_pixels = 100000000;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork[kRing] = {}, ev_join[kRing] = {};
-  // Chain hand-off (SEED_PIXEL with both exact accelerations on a single-level layout, from lpt_min_spp on):
+  // Chain hand-off (DESIGN 4.7 (HISTORY 4.10); SEED_PIXEL with both exact accelerations on a single-level layout, from lpt_min_spp on):
   // lanes push long pixel chains to server waves inside the same launch.  TOR_MIGRATE=0 restores split mode / the
   // wave-per-pixel kernel.  Knobs: TOR_SRV_FRAC (share of the workgroups that start as servers when the frame can hold a
   // chain above the threshold's floor), TOR_SRV_MIN_FRAC (otherwise), TOR_SRV_PATIENCE_US (a dedicated server without work

@@ -41,7 +41,7 @@
 //     "cooperative resolve" below).
 //
 //   coop_pixel_kernel  TOR_SEED_PIXEL, one WAVE per pixel chain: whole small frames, or -- split mode -- the most
-//                      expensive tiles of a mid-size frame while integrate_kernel renders the rest
+//                      expensive tiles of a mid-size frame while integrate_kernel renders the rest (DESIGN 4.7 (HISTORY 4.7-4.8)
 //   tile_order_kernel  counting sort of the SEED_PIXEL tiles by probed cost (LPT schedule) + the split point
 //   gather_rows_kernel multi-GPU assembly: rank-major row shards -> frame in image order
 //   finalize_kernel    canvas.nim:47-54 (draw): pow(sum * 1/spp, 1/gamma)
@@ -57,7 +57,7 @@
 //   kernel/integrate_refill.inc          (A) work distribution + camera ray
 //   kernel/integrate_loop_*.inc          (B) the wave-uniform object loop, one file per segment family:
 //                                        plane (ARITH 2, common-height segments: the plane screen for every object, then the
-//                                        second form per lane on what it keeps -- DESIGN.md 4.14), screen2 (ARITH 2 second-form
+//                                        second form per lane on what it keeps -- DESIGN 4.2), screen2 (ARITH 2 second-form
 //                                        records, wave-uniform -- 4.12), f64_static, f64_movers, f32 (TOR_ACCEL_F32),
 //                                        boxes32 / boxes64 (TOR_ACCEL_BLOCKS)
 //   kernel/integrate_resolve_lane.inc    exact float64 tests of the candidates, per lane
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   // one register too many while the pixel sum still lived in registers: 1-2 % slower then, 1-2 % faster at 100 spp now.)
   constexpr bool kPrio = SEEDING == 0;
   bool exhausted = false;
-  // ---- chain hand-off -------------------------------------------------------------------------------
+  // ---- chain hand-off (DESIGN 4.7 (HISTORY 4.10)) -------------------------------------------------------------------------------
   // A pixel is a sequential chain of spp samples (render.nim:59-67) and a lane needs ~16 us per bounce of it, so a frame
   // cannot end before its longest chain x 16 us -- that, not the machine, bounds small frames, row shards of a multi-GPU
   // job and the glass pixels of any frame.  Lanes therefore hand chains over at a sample boundary (state = pixel, samples

@@ -88,7 +88,7 @@ struct KParams {
   int n_cold_slots, coop_slots;
   const unsigned long long* split;  // split mode: number of cost-ordered tiles the wave kernel takes (device word), else null
   const double* coop_trips;  // 4 float64 per trip of 64 slots {kind, time0, time1 - time0, 0} (tor_scene.hpp)
-  // SEED_PIXEL chain hand-off (tor_kernels.hip "chain servers"); null = off.  Lanes push the state of a pixel
+  // SEED_PIXEL chain hand-off (tor_kernels.hip "chain servers", DESIGN 4.7 (HISTORY 4.10)); null = off.  Lanes push the state of a pixel
   // chain at a sample boundary -- {pixel, samples done, RNG state, running sum} -- and whole waves ("servers") continue it,
   // the 64 lanes sharing each closest-hit query: same arithmetic, same pixel, a tenth of the latency per bounce.
   unsigned long long* mig;      // control words, kMig* below (zero before the launch; tile_order_kernel fills the schedule part)

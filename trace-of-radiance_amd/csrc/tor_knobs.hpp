@@ -43,7 +43,7 @@ constexpr Knob kKnobs[] = {
     {"TOR_HOT_FRAC", "0.4", ">= 0", "context", "a pixel chain is HOT (arbiter priority 3) from this share of an average wave's iterations; 0 = off"},
     {"TOR_PRIO_SHIFT", "16", "0..31", "context", "arbiter-priority rotation period, log2 shader-clock ticks; 0 = off"},
     {"TOR_SPLIT_FRAC", "(automatic)", "0..1", "context", "split mode: share of the probed cost that goes to the wave-per-pixel kernel; 0 = off"},
-    // ---- TOR_SEED_PIXEL chain hand-off ----
+    // ---- TOR_SEED_PIXEL chain hand-off (DESIGN 4.7 (HISTORY 4.10)) ----
     {"TOR_MIGRATE", "1", "0 | 1", "context", "0: no chain hand-off (split mode / wave-per-pixel kernel instead)"},
     {"TOR_SRV_FRAC", "0.07", "0..1", "context", "share of the workgroups that start as servers when the frame can hold a chain above the threshold's floor"},
     {"TOR_SRV_MIN_FRAC", "0.005", "0..1", "context", "... otherwise"},
