@@ -188,6 +188,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
     } else {
       members = all_members;
     }
+    const size_t big_at = segs64.size();   // (the leftovers below join the big spheres' segment when both are small: see there)
     if (!big.empty()) segs64.push_back({kind, big, t0, dt, xkind_rest, 0.0});
     if (members.empty()) return;
     std::vector<std::pair<uint64_t, std::vector<int64_t>>> by_y;  // in order of first appearance
@@ -218,6 +219,12 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
       }
     } else {
       rest = members;
+    }
+    // a handful of leftovers and a handful of big spheres: ONE segment (fewer than 48 objects never run stage one -- the gate in
+    // xhdr -- so the band's width, the reason for setting the big ones apart, does not matter; a segment's set-up does)
+    if (!rest.empty() && !big.empty() && rest.size() + big.size() < 48) {
+      segs64[big_at].ids.insert(segs64[big_at].ids.end(), rest.begin(), rest.end());
+      rest.clear();
     }
     if (!rest.empty()) segs64.push_back({kind, rest, t0, dt, xkind_rest, 0.0});
     for (Seg64& u : uniform) segs64.push_back(std::move(u));
