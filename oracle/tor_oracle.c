@@ -621,7 +621,12 @@ static V3 radiance(Ray ray, const Obj* objs, int64_t n, int max_depth, Rng* g,
   return v3(0, 0, 0);
 }
 
-/* Round x to the nearest multiple of 2^-36 (ties to even); exact for |x| < 2^15. */
+/* Round x to the nearest multiple of 2^-36 (ties to even); exact for |x| < 2^15.
+ * Distance between the two accumulations this oracle offers (ACCUM_QUANTIZED: what TOR_SEED_SAMPLE sums on the GPU, exact in any
+ * order; ACCUM_SEQUENTIAL: render.nim:67's plain float64 sum): every sample moves by at most 2^-37, so the sum of spp samples by
+ * at most spp * 2^-37 before canvas.nim:49's 1/spp -- 2^-37 = 7.3e-12 per channel after it, whatever spp -- plus the sequential
+ * sum's own roundings (spp * 2^-53 * |sum|).  Measured on a row of BASELINE configs[3] (3840x2160, 4096 spp) against the
+ * PNG-pinned LIBM / SEQUENTIAL mode: 1.3e-11 (tests/test_gpu_round5.py); the stated tolerance is 1e-5. */
 static inline double quantize36(double x) {
   volatile double m = 98304.0; /* 1.5 * 2^16 : ulp = 2^-36 */
   volatile double t = x + m;
