@@ -298,12 +298,20 @@ def cpu_baseline(width, height, spp, depth, target_seconds):
     rate = 216 * 384 * 100 / max(c1_dt, 1e-6)
     # a bounded sample of the bench frame: evenly spaced rows, parallelised over (row, 16-column) tiles so that a
     # few rows still load every core (Weave, too, splits rows and then columns)
+    # ... in TWO halves (rows 0, 2k, 4k, ... and rows k, 3k, 5k, ...): the two rates bracket the run-to-run and row-to-row spread of a
+    # sample this small (+-10 % between runs), the value is their pooled rate
     want_rows = int(min(height, max(4, rate * target_seconds / (width * spp))))
     step = max(1, height // max(want_rows, 1))
-    rows = len(range(0, height, step))
-    t = time.perf_counter()
-    O.render(height, width, spp, cam, objs, max_depth=depth, row_step=step, col_block=16)
-    dt = time.perf_counter() - t
+    halves = []
+    for begin in (0, step):
+        n_rows = len(range(begin, height, 2 * step))
+        if n_rows == 0:
+            continue
+        t = time.perf_counter()
+        O.render(height, width, spp, cam, objs, max_depth=depth, rows=(begin, height), row_step=2 * step, col_block=16)
+        halves.append((n_rows, time.perf_counter() - t))
+    rows = sum(n for n, _ in halves)
+    dt = sum(d for _, d in halves)
     samples = rows * width * spp
     model = "unknown"
     try:
@@ -320,6 +328,8 @@ def cpu_baseline(width, height, spp, depth, target_seconds):
                   f"depth {depth}: {samples / 1e6:.1f} Msamples in {dt:.1f} s; oracle/tor_oracle.c faithful mode "
                   f"(seed(row,col) streams, libm, -ffp-contract=off), OpenMP schedule(dynamic,1) over (row, 16-column) tiles",
         "cpu_model": model,
+        "halves": [round(n * width * spp / d / 1e6, 4) for n, d in halves],
+        "spread": "the two interleaved halves of the row sample, timed separately (Msamples/s): their difference is the noise of `value`",
         "c1": {"workload": "BASELINE configs[0]: 384x216, 100 spp, depth 50 (trace_of_radiance.nim main())",
                "value": round(216 * 384 * 100 / c1_dt / 1e6, 4), "seconds": round(c1_dt, 3),
                "ppm_equals_reference_png": png_equal, "ppm_vs_png": png_note},
