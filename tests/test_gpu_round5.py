@@ -134,6 +134,29 @@ def test_configs3_row_against_the_pinned_libm_oracle(tor, oracle, ref_scene, ref
     assert err < 1e-8, err           # what is actually observed: the bound above plus the last-ulp differences of sin / cos / pow
 
 
+def test_non_finite_ray_time_hits_statics_only(tor, oracle, ref_scene):
+    """A camera whose shutter never closes (shutter_close = inf) gives every camera ray time = inf (cameras.nim:56): the
+    reference's moving spheres get non-finite centres and can never be hit, its static spheres are hit as ever -- and rays
+    scattered by metal / glass carry time 0 again (rays.nim:19).  Round 5 put random_scene's resting statics into the resting
+    movers' segment (dc = 0): the screened loop, the wave-uniform loops and the unscreened loop must still find them at a
+    non-finite time fraction (integrate_loop_f64_movers.inc; tor_screen.hpp: a wild ray keeps everything).  == the oracle."""
+    import torch
+    objs, _ = ref_scene
+    scene = tor.random_scene(0xFACADE)
+    cam = tor.camera(shutter_open=0.0, shutter_close=float("inf"))
+    ocam = oracle.camera(shutter_open=0.0, shutter_close=float("inf"))
+    h, w, spp = 54, 96, 8
+    for seeding in (0, 1):
+        want = oracle.render(h, w, spp, ocam, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels
+        assert np.isfinite(want).all() and float(want.sum()) > 0.0
+        for env in ({}, {"TOR_PLANE": "0"}, {"TOR_PLANE": "2"}, {"TOR_SCREEN": "0"}):
+            got, _ = _render_with_env(tor, scene, cam, h, w, spp, env, seeding=seeding, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+            _exact(got.cpu().numpy(), want)
+        for accel in (1, 2, 3):
+            got, _ = _render_with_env(tor, scene, cam, h, w, spp, {}, seeding=seeding, accel=accel, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+            _exact(got.cpu().numpy(), want)
+
+
 def test_fused_arithmetic_is_refused_with_the_reason(tor):
     """Round 5 removed the TOR_ARITH_FUSED kernel variants (not the reference's rounding, README.md:82); the enum value stays
     reserved so that a caller of rounds 1-4 fails loudly instead of silently getting another arithmetic."""
