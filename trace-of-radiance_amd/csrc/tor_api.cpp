@@ -572,7 +572,7 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       q.xrec_lds_doubles = 0;
       if (q.xpl != nullptr && ctx->screen && accel == 0) {
         const size_t wgs = (size_t)std::max(1, ctx->max_blocks_per_cu[o.seeding][0]);
-        const size_t need = (size_t)L.n_xrec * 8 + (size_t)tor::integrate_fixed_lds_bytes(0, 0);
+        const size_t need = (size_t)L.n_xrec * 8 + (size_t)tor::integrate_fixed_lds_bytes(0, 0, o.seeding);
         if (need <= (size_t)(160 * 1024) / wgs - 1024 && need <= (size_t)64 * 1024) q.xrec_lds_doubles = L.n_xrec;
       }
       q.n_segs = L.n_segs;

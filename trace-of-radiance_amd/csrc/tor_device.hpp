@@ -99,6 +99,12 @@ TOR_HD double uniform_range_of(uint64_t out, double lo, double hi) {
 }
 template <class G>
 TOR_HD double uniform_range(G& g, double lo, double hi) { return uniform_range_of(next(g), lo, hi); }
+// uniform_range(g, -1.0, 1.0) without the comparison: d is in [0, 1), so v = d * 2.0 + -1.0 >= -1.0 = lo, and `v <= lo` can only
+// hold with v == lo, where the reference's max returns lo -- the same bits.  (Three of these per trip of the rejection loops, which
+// a wave runs until its unluckiest lane accepts.)
+TOR_HD double uniform_pm1_of(uint64_t out) { return uniform01_of(out) * (1.0 - -1.0) + -1.0; }
+template <class G>
+TOR_HD double uniform_pm1(G& g) { return uniform_pm1_of(next(g)); }
 
 // ---------------------------------------------------------------------------------------
 // Samplers -- sampling.nim
@@ -107,8 +113,8 @@ TOR_HD double uniform_range(G& g, double lo, double hi) { return uniform_range_o
 template <class G>
 TOR_HD V3 random_in_unit_disk(G& g) {
   for (;;) {
-    double x = uniform_range(g, -1.0, 1.0);
-    double y = uniform_range(g, -1.0, 1.0);
+    double x = uniform_pm1(g);
+    double y = uniform_pm1(g);
     if (x * x + y * y + 0.0 * 0.0 < 1.0) return V3{x, y, 0.0};
   }
 }
@@ -116,9 +122,9 @@ TOR_HD V3 random_in_unit_disk(G& g) {
 template <class G>
 TOR_HD V3 random_in_unit_sphere(G& g) {
   for (;;) {
-    double x = uniform_range(g, -1.0, 1.0);
-    double y = uniform_range(g, -1.0, 1.0);
-    double z = uniform_range(g, -1.0, 1.0);
+    double x = uniform_pm1(g);
+    double y = uniform_pm1(g);
+    double z = uniform_pm1(g);
     V3 p{x, y, z};
     if (len2(p) < 1.0) return p;
   }
@@ -126,7 +132,7 @@ TOR_HD V3 random_in_unit_sphere(G& g) {
 // sampling.nim:51-55, from the two outputs it draws
 TOR_HD V3 random_unit_vector_of(uint64_t out_a, uint64_t out_z) {
   double a = uniform_max_of(out_a, 2.0 * 3.141592653589793);
-  double z = uniform_range_of(out_z, -1.0, 1.0);
+  double z = uniform_pm1_of(out_z);
   double r = __builtin_sqrt(1.0 - z * z);
   double s, c;
   sincos_2pi(a, s, c);
@@ -134,7 +140,7 @@ TOR_HD V3 random_unit_vector_of(uint64_t out_a, uint64_t out_z) {
 }
 TOR_HD V3 random_unit_vector(Rng& g) {
   double a = uniform_max(g, 2.0 * 3.141592653589793);
-  double z = uniform_range(g, -1.0, 1.0);
+  double z = uniform_pm1(g);
   double r = __builtin_sqrt(1.0 - z * z);
   double s, c;
   sincos_2pi(a, s, c);

@@ -140,15 +140,20 @@ constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 
 constexpr int kCoopList = 576;
 // (+ the paths' attenuation: 3 x 64 float64 -- touched once per bounce, so it lives in LDS, not in 6 of the 168 registers)
 constexpr int coop_bytes(int blocks) { return (blocks ? 2 : 1) * kCoopList * 4 + 64 * 2 * 8 + 3 * 64 * 8; }  // (no pair list without boxes)
-constexpr int wave_lds_bytes(int blocks, int coop = 0) {
-  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) + 64 : 0);
+// Camera-ray reservoir (TOR_SEED_SAMPLE, float64 brute force: kernel/integrate_refill.inc): 64 started samples per wave --
+// generator state after the camera ray (4 x u64), lens offsets, film coordinates, time (5 x f64), pixel as a byte offset from
+// the batch's first pixel (+ that pixel, 16-byte padded)
+constexpr bool reservoir_variant(int seeding, int f32, int blocks) { return seeding == 1 && f32 == 0 && blocks == 0; }
+constexpr int kResBytes = 9 * 64 * 8 + 64 + 16;
+constexpr int wave_lds_bytes(int blocks, int coop = 0, int res = 0) {
+  return queue_cap(blocks) * 64 * 4 + kAccSlots * 3 * 8 + kAccSlots * 4 + kProfSlots * 8 + (coop ? coop_bytes(blocks) + 64 : 0) + (res ? kResBytes : 0);
 }
 // Which kernel variants resolve cooperatively: TOR_ACCEL_BLOCKS | TOR_ACCEL_F32.  (The code also runs the variants
 // without boxes -- `blocks == 0 || f32 != 0` passes every parity test -- but there the candidates are few (1.25-1.43
 // per query): a pooled trip costs twice a per-lane trip, the resolve share stays at 5-6 % and the extra LDS and
 // registers cost the float64 brute force 2 % (C3 1190 -> 1163 Msamples/s).  Measured, not kept.)
 constexpr bool coop_variant(int f32, int blocks) { return blocks != 0 && f32 != 0; }
-static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0 && wave_lds_bytes(1, 1) % 16 == 0 && wave_lds_bytes(0, 1) % 16 == 0,
+static_assert(wave_lds_bytes(0) % 16 == 0 && wave_lds_bytes(1) % 16 == 0 && wave_lds_bytes(1, 1) % 16 == 0 && wave_lds_bytes(0, 1) % 16 == 0 && kResBytes % 16 == 0,
               "keep LDS carve-outs 16-byte aligned");
 
 // The camera (24 float64) is needed once per new path only; read it there instead of keeping
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   constexpr int kQLayout = queue_cap(BLOCKS);          // queue entries the LDS layout reserves
   constexpr int kQCap = kAccInLds ? 4 : kQLayout;      // ... and the ones this variant uses
   constexpr int kAccPad = coop_variant(F32, BLOCKS) ? 64 : 0;
-  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS, coop_variant(F32, BLOCKS));
+  constexpr bool kRes = reservoir_variant(SEEDING, F32, BLOCKS);
+  constexpr int kWaveLdsBytes = wave_lds_bytes(BLOCKS, coop_variant(F32, BLOCKS), kRes);
   unsigned char* wave_lds = smem_raw + wave * kWaveLdsBytes;
   unsigned* q = reinterpret_cast<unsigned*>(wave_lds) + lane;  // q[k * 64]: k-th entry of this lane
   double* acc_lds = reinterpret_cast<double*>(wave_lds + kQLayout * 64 * 4);          // [kAccSlots][3]
@@ -235,6 +241,11 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned* coop_surv = reinterpret_cast<unsigned*>(coop_w + 64);                  // [kCoopList] lane | cold slot << 6
   unsigned* coop_pair = coop_surv + kCoopList;                                     // [kCoopList] lane | block << 6 (BLOCKS variants only)
   double* coop_att = reinterpret_cast<double*>(coop_pair + kCoopList) + lane;      // [3][64] the paths' attenuation (coop variants)
+  // camera-ray reservoir (kRes variants: no cooperative state, so it starts where that would)
+  unsigned long long* res_rng = reinterpret_cast<unsigned long long*>(coop_base);  // [4][64] generator state after the camera ray
+  double* res_f = reinterpret_cast<double*>(coop_base + 4 * 64 * 8);               // [5][64] lens offset x, y; film s, t; time
+  unsigned char* res_dp = coop_base + 9 * 64 * 8;                                  // [64] pixel - first pixel of the batch
+  unsigned* res_pl0 = reinterpret_cast<unsigned*>(coop_base + 9 * 64 * 8 + 64);    // first pixel of the batch
 
   const cdptr stat = as_const(p.stat);
   const cdptr mov = as_const(p.mov);
@@ -303,6 +314,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   unsigned long long w_next = 0, w_end = 0;
   unsigned cur_pl = 0, cur_s = 0;
   unsigned next_chunk = p.chunk;
+  unsigned res_head = 0, res_cnt = 0;  // kRes: the camera-ray reservoir's next entry and fill (kernel/integrate_refill.inc)
   const unsigned prio_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_ID.wave_id: the wave's slot in its SIMD
   unsigned prio_now = 0;
   // a pixel chain is HOT when, extrapolated from its samples so far, it needs more than hot_iters bounce iterations
@@ -713,8 +725,8 @@ static int clamp_w(int waves_per_simd) {
 
 static int wants_f32(const KParams& p) { return (p.hot32 != nullptr || p.shot32 != nullptr) ? 1 : 0; }
 static int wants_blocks(const KParams& p) { return p.bnd != nullptr ? ((p.two_level != 0 && wants_f32(p) != 0) ? 2 : 1) : 0; }
-static size_t dynamic_lds(const KParams& p) {
-  return (size_t)wave_lds_bytes(wants_blocks(p), coop_variant(wants_f32(p), wants_blocks(p))) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
+static size_t dynamic_lds(const KParams& p, int seeding) {
+  return (size_t)wave_lds_bytes(wants_blocks(p), coop_variant(wants_f32(p), wants_blocks(p)), reservoir_variant(seeding, wants_f32(p), wants_blocks(p))) * (kThreads / 64) + (size_t)p.shot_lds_doubles * 8 + (size_t)p.shot32_lds_floats * 4 +
          (size_t)p.bnd32_lds_floats * 4 +
          // (the second-form table of stage two: only the ARITH 2 variants -- brute-force layouts behind the screen -- stage it)
          ((p.screen != 0 && wants_f32(p) == 0 && wants_blocks(p) == 0) ? (size_t)p.xrec_lds_doubles * 8 : (size_t)0);
@@ -729,7 +741,7 @@ static int arith_variant(const KParams& p, int arith) {
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream) {
   IntegrateFn fn = integrate_variant(2, arith_variant(p, 0), 3, wants_f32(p), wants_blocks(p));
   if (!fn) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p), stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p, 2), stream, p);
   return hipGetLastError();
 }
 
@@ -758,14 +770,14 @@ hipError_t launch_integrate(const KParams& p, int seeding, int arith, int waves_
                             hipStream_t stream) {
   IntegrateFn fn = integrate_variant(seeding, arith_variant(p, arith), clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
   if (!fn) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p), stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), dynamic_lds(p, seeding), stream, p);
   return hipGetLastError();
 }
 
 int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_per_simd) {
   IntegrateFn fn = integrate_variant(seeding, arith_variant(p, arith), clamp_w(waves_per_simd), wants_f32(p), wants_blocks(p));
   int n = 0;
-  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, dynamic_lds(p)) != hipSuccess || n < 1) n = 1;
+  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kThreads, dynamic_lds(p, seeding)) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
@@ -792,7 +804,9 @@ hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stre
   return hipGetLastError();
 }
 
-int integrate_fixed_lds_bytes(int blocks, int coop) { return wave_lds_bytes(blocks, coop) * (kThreads / 64); }
+int integrate_fixed_lds_bytes(int blocks, int coop, int seeding) {
+  return wave_lds_bytes(blocks, coop, reservoir_variant(seeding, coop, blocks)) * (kThreads / 64);
+}
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {
   if (n_values <= 0) return hipSuccess;
