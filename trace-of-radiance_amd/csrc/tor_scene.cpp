@@ -270,6 +270,11 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
       break;
     }
   }
+  // The largest segment first: the screened loop works through the sorted list in words of 32 slots, and a segment that begins on
+  // a word boundary runs whole words from its first object (kernel/integrate_loop_plane.inc: a word costs 21 scalar instructions,
+  // the same 32 slots as four blocks of 8 cost ~230).  random_scene: 481 resting spheres, then the ground and the three big ones
+  // -- 15 words and 2 blocks where the order of appearance (big spheres first) gave 14 words and 6 blocks.
+  std::stable_sort(segs64.begin(), segs64.end(), [](const Seg64& a, const Seg64& b) { return a.ids.size() > b.ids.size(); });
   // (a member of a mover segment as a mover: a static sphere that joined one is c0 == c1)
   auto as_mover = [&](int64_t idx) {
     if (objs[idx].kind == TOR_MOVING_SPHERE) return objs[idx].u.moving_sphere;
