@@ -198,10 +198,10 @@ def test_last_render_timing_means_what_the_header_says(tor):
     cv = tor.new_canvas(540, 960, 300, 2.2)
     opt = tor.make_options(seeding=tor.SEED_SAMPLE)
     tor.render(cv, cam, scene.list(), 50, opt)
-    tor.render(cv, cam, scene.list(), 50, opt)     # ~130 ms of kernel, ~3 ms of D2H
+    tor.render(cv, cam, scene.list(), 50, opt)     # ~50 ms of kernel (round 5; 130 ms when the test was written), ~0.5 ms of D2H
     t = tor.last_render_timing()
     assert t["scene_cache_hit"] and t["upload_ms"] < 5.0
-    assert t["render_ms"] > 50.0 and t["render_ms"] > 10.0 * t["download_ms"], t
+    assert t["render_ms"] > 20.0 and t["render_ms"] > 10.0 * t["download_ms"], t
     assert abs(t["upload_ms"] + t["render_ms"] + t["download_ms"] - t["total_ms"]) < 0.1 * t["total_ms"] + 1.0, t
 
 
