@@ -240,7 +240,7 @@ static const dd DD_LN2 = { 0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56 };
 /* sin and cos of a in [0, 8): the argument range the path produces is
  * [0, 2*pi) (sampling.nim:52).  Both results are the double nearest to the exact
  * value except with probability ~2^-17 per call. */
-static void port_sincos(double a, double* s_out, double* c_out) {
+static void port_sincos_slow(double a, double* s_out, double* c_out) {
   if (!(a >= 0.0 && a < 8.0)) { *s_out = sin(a); *c_out = cos(a); return; } /* off-path */
   int k = (int)(a * TWO_OVER_PI + 0.5);
   double fk = (double)k;
@@ -275,6 +275,85 @@ static void port_sincos(double a, double* s_out, double* c_out) {
     default: *s_out = -C; *c_out = S; break;
   }
 }
+
+/* ---- sincos: fast path (round 5).  The double-double evaluation above costs ~290 float64 operations per call and the GPU runs it
+ * on every bounce iteration of every wave (sampling.nim:51-55 through materials.nim:24-30).  The fast path gets the SAME doubles
+ * -- both are the correctly rounded value -- from ~85 operations and PROVES it per call (Ziv's rounding test); a call whose test
+ * fails (~1 in 600) takes the double-double path.  csrc/tor_math.hpp carries the same operations in the same order.
+ *   a = j h + r, h = pi/128, |r| <= h/2 (+ one rounding of a * 128/pi); r = rh + rl to ~2^-125 (H1, H2 short: j * H1 and j * H2 are
+ *     exact for j <= 256, a - j * H1 is exact by Sterbenz's lemma);
+ *   sin r - r = rh z ps(z), cos r - 1 = -z/2 + ce, z = rh^2 (Taylor to r^9 / z^4: truncation < 2^-69 at |r| <= 0.0124);
+ *   sin a = S (1 + (cos r - 1)) + C (r + (sin r - r)) with (S, C) = sin, cos(j h) from a table of double-doubles: the large terms
+ *     S.hi, C.hi rh, S.hi (-z/2) enter exactly (two_prod, fast_two_sum), the rest in one correction of relative size < 2^-14
+ *     whose roundings stay below 2^-66 of the result; cos a likewise with (C, -S).
+ *   Rounding test: the result is h + corr with |error| < 2^-64 |h| (measured: < 2^-65.6 over 4e6 arguments against mpmath,
+ *     tests/test_oracle_math.py); if h + (corr - 2^-64 |h|) and h + (corr + 2^-64 |h|) round to the same double, that double is
+ *     the correctly rounded value. */
+static const double SINCOS_TAB[257 * 4] = {
+#include "tor_sincos_table.inc"
+};
+#define SC_INV_H 0x1.45f306dc9c883p+5
+#define SC_H1 0x1.921fb54000000p-6
+#define SC_H2 0x1.10b4611a62600p-36
+#define SC_H3 0x1.98a2e03707345p-83
+#define SC_EPS 0x1p-64
+static inline int sc_ziv(double h, double corr, double* out) {
+  const double e = fabs(h) * SC_EPS;
+  const double r1 = h + (corr + e), r2 = h + (corr - e);
+  *out = r1;
+  return r1 == r2;
+}
+/* returns 1 when both results passed the rounding test */
+static int port_sincos_fast_parts(double a, double* s_out, double* c_out, double* parts) {
+  if (!(a >= 0.0 && a < 6.2890625)) return 0;   /* j <= 256 */
+  const int j = (int)(a * SC_INV_H + 0.5);
+  const double fj = (double)j;
+  const double r0 = fma(-fj, SC_H1, a);         /* exact */
+  const dd r = two_sum(r0, -(fj * SC_H2));      /* fj * H2 exact */
+  const double rh = r.hi, rl = fma(-fj, SC_H3, r.lo);
+  const double z = rh * rh, zl = fma(rh, rh, -z);
+  const double ps = fma(fma(fma(0x1.71de3a556c734p-19, z, -0x1.a01a01a01a01ap-13), z, 0x1.1111111111111p-7), z, -0x1.5555555555555p-3);
+  const double sr = (rh * z) * ps;                                  /* sin r - r */
+  const double pc = fma(fma(0x1.a01a01a01a01ap-16, z, -0x1.6c16c16c16c17p-10), z, 0x1.5555555555555p-5);
+  const double hz = -0.5 * z;                                       /* exact */
+  const double ce = fma(z * z, pc, fma(-0.5, zl, -(rh * rl)));      /* cos r - 1 - hz */
+  const double t = rl + sr;
+  const double* T = SINCOS_TAB + 4 * j;
+  const double Sh = T[0], Sl = T[1], Ch = T[2], Cl = T[3];
+  int ok;
+  {
+    const dd p = two_prod(Ch, rh), q = two_prod(Sh, hz);
+    const dd u = fast_two_sum(Sh, p.hi);
+    const dd v = fast_two_sum(u.hi, q.hi);
+    double corr = ((u.lo + v.lo) + (p.lo + q.lo)) + fma(Sl, hz, Sl);
+    corr = fma(Cl, rh, corr);
+    corr = fma(Sh, ce, corr);
+    corr = fma(Ch, t, corr);
+    ok = sc_ziv(v.hi, corr, s_out);
+    if (parts) { parts[0] = v.hi; parts[1] = corr; }
+  }
+  {
+    const dd p = two_prod(Sh, rh), q = two_prod(Ch, hz);
+    const dd u = fast_two_sum(Ch, -p.hi);
+    const dd v = fast_two_sum(u.hi, q.hi);
+    double corr = ((u.lo + v.lo) + (q.lo - p.lo)) + fma(Cl, hz, Cl);
+    corr = fma(-Sl, rh, corr);
+    corr = fma(Ch, ce, corr);
+    corr = fma(-Sh, t, corr);
+    ok &= sc_ziv(v.hi, corr, c_out);
+    if (parts) { parts[2] = v.hi; parts[3] = corr; }
+  }
+  return ok;
+}
+static int port_sincos_fast(double a, double* s_out, double* c_out) { return port_sincos_fast_parts(a, s_out, c_out, NULL); }
+static void port_sincos(double a, double* s_out, double* c_out) {
+  if (!port_sincos_fast(a, s_out, c_out)) port_sincos_slow(a, s_out, c_out);
+}
+/* MATH_LIBM: sampling.nim:54 calls sin(a) and cos(a); gcc -O2 merges two such calls in one function into ONE sincos() -- it does
+ * for the C that Nim emits, and it did for this file when tests/golden/small_canvases.npz was generated -- and glibc's sincos()
+ * differs from its sin() / cos() by an ulp now and then.  Whether gcc merged depended on what else the function inlined (round 5:
+ * a larger port_sincos turned the merge off and moved one sample of the fixtures by an ulp), so the call is spelled out. */
+extern void sincos(double, double*, double*);
 
 /* x^5, correctly rounded w.h.p. (what a correctly rounded pow(x,5) returns). */
 static double port_pow5(double x) {
@@ -429,7 +508,7 @@ static V3 random_unit_vector(Rng* g, int math_mode, OracleStats* st) {
   double z = uniform_range(g, -1.0, 1.0, st);
   double r = sqrt(1.0 - z * z);
   double s, c;
-  if (math_mode == 0) { s = sin(a); c = cos(a); } else port_sincos(a, &s, &c);
+  if (math_mode == 0) sincos(a, &s, &c); else port_sincos(a, &s, &c);
   return v3(r * c, r * s, z);
 }
 
@@ -774,6 +853,11 @@ EXPORT uint64_t oracle_rng_next(uint64_t state[4]) { Rng g; memcpy(&g, state, 32
 EXPORT double oracle_rng_uniform01(uint64_t state[4]) { Rng g; memcpy(&g, state, 32); double r = uniform01(&g, NULL); memcpy(state, &g, 32); return r; }
 EXPORT double oracle_rng_uniform_range(uint64_t state[4], double lo, double hi) { Rng g; memcpy(&g, state, 32); double r = uniform_range(&g, lo, hi, NULL); memcpy(state, &g, 32); return r; }
 EXPORT void oracle_port_sincos(const double* a, double* s, double* c, int64_t n) { for (int64_t i = 0; i < n; ++i) port_sincos(a[i], &s[i], &c[i]); }
+/* the double-double path alone, and the fast path alone with its verdict (tests) */
+EXPORT void oracle_port_sincos_slow(const double* a, double* s, double* c, int64_t n) { for (int64_t i = 0; i < n; ++i) port_sincos_slow(a[i], &s[i], &c[i]); }
+EXPORT void oracle_port_sincos_fast(const double* a, double* s, double* c, int32_t* ok, double* parts, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) ok[i] = port_sincos_fast_parts(a[i], &s[i], &c[i], parts ? parts + 4 * i : NULL);
+}
 EXPORT void oracle_port_pow5(const double* x, double* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = port_pow5(x[i]); }
 EXPORT void oracle_port_pow(const double* x, double e, double* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = port_pow(x[i], e); }
 EXPORT void oracle_libm_sincos(const double* a, double* s, double* c, int64_t n) { for (int64_t i = 0; i < n; ++i) { s[i] = sin(a[i]); c[i] = cos(a[i]); } }
