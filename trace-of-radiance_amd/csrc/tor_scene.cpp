@@ -287,9 +287,24 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   // float64 per slot of the second-stage records (xrec) and of the plane table (xpl), by xkind
   auto xs_of = [](int xkind) { return xkind == 0 ? 0 : (xkind >= 13 ? 8 : 4); };
   auto pw_of = [](int xkind) { return xkind == 0 ? 0 : (xkind == 13 ? 4 : 2); };
+  // Slots per segment: padded to blocks of 8; a plane-screened segment whose tail would be three or four blocks is padded to the
+  // next WORD instead (32 slots: the tail runs as one whole word of stage one -- 131 vector + 21 scalar instructions -- where three
+  // blocks cost 96 + ~120, and every segment behind it starts on a word boundary: kernel/integrate_loop_plane.inc), unless
+  // that would push the sorted list into one more 512-slot pass.  random_scene is not affected (481 = 15 words + 1).
+  auto slots_of = [&](const Seg64& sg, bool words) {
+    size_t c = padded(sg.ids.size());
+    if (words && sg.xkind >= 10 && sg.ids.size() >= 48 && c % 32 > 16) c = (c + 31) / 32 * 32;
+    return c;
+  };
+  bool pad_words = true;
+  {
+    size_t t0 = 0, t1 = 0;
+    for (const Seg64& sg : segs64) { t0 += slots_of(sg, false); t1 += slots_of(sg, true); }
+    if ((t1 + 511) / 512 > (t0 + 511) / 512) pad_words = false;
+  }
   size_t n_stat_p = 0, n_mov_p = 0, n_movy_p = 0, n_xrec = 0, n_xpl = 0;
   for (const Seg64& sg : segs64) {
-    const size_t cp = padded(sg.ids.size());
+    const size_t cp = slots_of(sg, pad_words);
     (sg.kind == 0 ? n_stat_p : (sg.kind == 1 ? n_movy_p : n_mov_p)) += cp;
     n_xrec += cp * (size_t)xs_of(sg.xkind);
     n_xpl += cp * (size_t)pw_of(sg.xkind);
@@ -326,7 +341,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
   auto up = [](double x) { return x * (1.0 + 0x1p-40); };
   size_t sorted = 0, stat_rec = 0, mov_rec = 0, movy_rec = 0, x_off = 0, pl_off = 0;
   for (const Seg64& sg : segs64) {
-    const size_t cnt_p = padded(sg.ids.size());
+    const size_t cnt_p = slots_of(sg, pad_words);
     double reach = 0.0, travel = 0.0, rmax2 = 0.0;
     // bounding box of the centres' ground projection (+ the movers' travel): what plane_pays (tor_screen.hpp) weighs the band against
     double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY, dcx_max = 0.0, dcz_max = 0.0;
