@@ -51,6 +51,28 @@ def _wall_scene(tor, n=20):
     return tor.Scene.from_records(np.asarray(recs, dtype=np.float64))
 
 
+def _ragged_segments_scene(tor, rng):
+    """Segment sizes that exercise the layout's tails (tor_scene.cpp, round 5): 50 statics at one height (tail of 18 -> padded to
+    a word of stage one), 83 movers along y at another (88 slots, tail of 24 -> padded to 96), 36 movers in general position (below
+    the plane screen's 48: blocks only), 9 statics at a third height (one whole block + a last block with ONE real slot: the
+    half-block path), the ground and two big spheres (a half-real only block)."""
+    recs = [[0, 0, -1000, 0, 0, -1000, 0, 0, 1, 1000, 0, .5, .5, .5, 0, 0],
+            [0, 0, 1, 0, 0, 1, 0, 0, 1, 1.0, 2, 0, 0, 0, 0, 1.5], [0, 4, 1, 0, 4, 1, 0, 0, 1, 1.0, 1, .7, .6, .5, 0.0, 0]]
+    def xz():
+        return rng.uniform(-9, 9, 2)
+    for i in range(50):
+        x, z = xz(); recs.append([0, x, 0.2, z, x, 0.2, z, 0, 1, 0.2, i % 3, .6, .5, .4, 0.2, 1.5])
+    for i in range(83):
+        x, z = xz(); recs.append([1, x, 0.25, z, x, 0.25 + rng.uniform(0, .5), z, 0.0, 1.0, 0.25, i % 3, .3, .7, .4, 0.1, 1.5])
+    for i in range(36):
+        x, z = xz(); y = rng.uniform(0.3, 3.0)
+        recs.append([1, x, y, z, x + rng.uniform(-.4, .4), y + rng.uniform(-.3, .3), z + rng.uniform(-.4, .4), 0.0, 1.0, 0.2, i % 3, .3, .3, .8, 0.0, 1.4])
+    for i in range(9):
+        x, z = xz(); recs.append([0, x, 0.3, z, x, 0.3, z, 0, 1, 0.3, i % 3, .5, .5, .7, 0.3, 1.5])
+    order = rng.permutation(len(recs))
+    return tor.Scene.from_records(np.asarray(recs, dtype=np.float64)[order])
+
+
 def test_plane_screen_on_every_segment_kind(tor, oracle):
     """Round 4's stage one ran on segments that share c0.y bit for bit with movers along y only -- two coincidences of scenes.nim:24-36.
     The test itself never reads y (tor_screen.hpp), so round 5 runs it on every float64 segment: statics (xkind 10 / 11), movers
@@ -67,6 +89,7 @@ def test_plane_screen_on_every_segment_kind(tor, oracle):
               ("wall seen edge-on", _wall_scene(tor), tor.camera(look_from=(16, 3, 0.3), look_at=(0, 2, 0), aperture=0.02)),
               ("many heights", _many_heights_scene(tor, rng), tor.camera(look_from=(11, 2.2, 5), aperture=0.05)),
               ("three time groups, hollow spheres, glass", _screen_scenes(tor)[1][1], tor.camera(look_from=(10, 2.5, 4), aperture=0.05)),
+              ("ragged segment tails", _ragged_segments_scene(tor, rng), tor.camera(look_from=(11, 2.5, 5), aperture=0.05)),
               ("animation frame 37 (1601 statics at distinct heights)", a_scene, a_cam)]
     h, w = 108, 192
     for name, scene, cam in scenes:
