@@ -566,7 +566,8 @@ int tor_render_device(TorContext* ctx, const TorCamera* cam, int32_t nrows, int3
       q.xpl = ctx->plane_screen != 0 ? L.xpl : nullptr;
       q.plane_gate2 = ctx->plane_screen == 2 ? 0.0 : 4.0 * tor::kPlaneGate * tor::kPlaneGate;
       // stage two of the plane-screened segments reads its records per lane: from LDS when the table fits beside the per-wave
-      // queues at this launch's workgroups per CU (random_scene: 15.9 KB + 18.7 KB of 53 KB) and inside the 64 KB a launch may
+      // queues -- and, with sample streams, the camera-ray reservoirs -- at this launch's workgroups per CU (random_scene: 15.9 KB + 18.7 KB
+      // + 18.8 KB of 53.3 KB) and inside the 64 KB a launch may
       // ask for without an opt-in, else through the vector cache.  Only the ARITH 2 variants stage it (brute-force layouts
       // behind the screen: tor_kernels.hip dynamic_lds), so the room is only counted there.
       q.xrec_lds_doubles = 0;

@@ -804,8 +804,8 @@ hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stre
   return hipGetLastError();
 }
 
-int integrate_fixed_lds_bytes(int blocks, int coop, int seeding) {
-  return wave_lds_bytes(blocks, coop, reservoir_variant(seeding, coop, blocks)) * (kThreads / 64);
+int integrate_fixed_lds_bytes(int blocks, int f32, int seeding) {
+  return wave_lds_bytes(blocks, coop_variant(f32, blocks), reservoir_variant(seeding, f32, blocks)) * (kThreads / 64);
 }
 
 hipError_t launch_finalize(double* pixels, long long n_values, double scale, double gamma, hipStream_t stream) {

@@ -136,7 +136,7 @@ int integrate_blocks_per_cu(const KParams& p, int seeding, int arith, int waves_
 size_t coop_lds_bytes(int coop_slots);
 int coop_blocks_per_cu(const KParams& p, int arith);  // 0: the objects do not fit LDS
 hipError_t launch_coop(const KParams& p, int arith, int blocks, hipStream_t stream);
-int integrate_fixed_lds_bytes(int blocks, int coop, int seeding = 0);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists)
+int integrate_fixed_lds_bytes(int blocks, int f32, int seeding = 0);  // per workgroup: queues, accumulator cache, debug counters (+ cooperative-resolve lists | the camera-ray reservoir)
 hipError_t launch_probe(const KParams& p, int blocks, hipStream_t stream);
 // schedule of the chain hand-off, computed on the device from the probe's total (tile_order_kernel): l_avg = probed queries x
 // lavg_scale = bounce iterations an average lane runs in this frame; dedicated server workgroups = srv_frac x blocks when a
