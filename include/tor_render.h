@@ -456,6 +456,11 @@ TOR_API int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, cons
 TOR_API int tor_debug_screen2_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d,
                                     const double* time, int8_t* keep, int32_t* kind_out, int8_t* pays_out, int64_t n_segs_out);
 
+/* The float64 layout's segments in the order the kernel walks them (tor_scene.cpp: largest first; a plane-screened segment's long
+ * tail padded to a whole word of 32 slots): out[4 * s + {0, 1, 2, 3}] = {xkind, objects, slots, first slot} for the first
+ * `max_segs` segments; *n_segs_out = the number of segments.  Host only. */
+TOR_API int tor_debug_layout_segments(TorHittableList world, int32_t* out, int64_t max_segs, int64_t* n_segs_out);
+
 /* Float32 slab test of the culling boxes on the HOST (same source as the kernel): ray i against the box [lo_i, hi_i].
  * keep[i] = the float32 test keeps the box, need[i] = the float64 slab test of the float64 path passes.
  * Correct iff need[i] != 0 implies keep[i] != 0. */

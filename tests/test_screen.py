@@ -296,3 +296,33 @@ def test_strict_layout_walk_on_the_host(tor):
         plane_segments = (np.isin(kind, (10, 11, 12, 13, 14)) & small)[None, :] & on_second_form
         assert np.count_nonzero(keep[plane_segments] == 0) > 0.8 * np.count_nonzero(plane_segments)   # most pairs end at stage one
         assert np.all(keep[:4][plane_segments[:4]] >= 1)            # vertical rays: the plane screen keeps everything
+
+
+def test_layout_segments_largest_first_and_tails_padded_to_words(tor):
+    """tor_scene.cpp, round 5: segments are laid out largest first (the largest starts on a word boundary of the sorted list); a
+    plane-screened segment (>= 48 objects) whose tail would be three or four blocks of 8 is padded to the next word of 32 slots,
+    unless that costs the list one more 512-slot pass; everything else is padded to blocks of 8."""
+    segs = tor.debug_layout_segments(tor.random_scene(0xFACADE).list())
+    assert segs == [(12, 481, 488, 0), (10, 4, 8, 488)]          # 15 whole words + one block, then {ground, three big spheres}
+    rng = np.random.default_rng(3)
+    def scene(sizes):   # statics at distinct common heights, one segment per height; radii alike
+        recs = []
+        for k, n in enumerate(sizes):
+            for _ in range(n):
+                x, z = rng.uniform(-9, 9, 2)
+                recs.append([0, x, 0.2 + 0.01 * k, z, x, 0.2 + 0.01 * k, z, 0, 1, 0.2, 0, .5, .5, .5, 0, 0])
+        return tor.Scene.from_records(np.asarray(recs, dtype=np.float64)).list()
+    segs = tor.debug_layout_segments(scene([50, 83, 36, 9, 100]))
+    assert [s[1] for s in segs] == [100, 83, 50, 36, 9]                 # largest first
+    by_n = {s[1]: s for s in segs}
+    assert by_n[100][2] == 104      # tail of 4 (+4 padding): one block, not padded to a word
+    assert by_n[83][2] == 96        # 88 slots, tail of 24 -> a whole word
+    assert by_n[50][2] == 64        # 56 slots, tail of 24 -> a whole word
+    assert by_n[36][2] == 40 and by_n[9][2] == 16   # below the plane screen's 48 objects: blocks only
+    first = 0
+    for s in segs:
+        assert s[3] == first and s[2] % 8 == 0
+        first += s[2]
+    # padding must not cost a pass: 9 segments of 50 are 504 slots in blocks, 576 in words -> stay in blocks
+    segs = tor.debug_layout_segments(scene([50] * 9))
+    assert all(s[2] == 56 for s in segs) and sum(s[2] for s in segs) == 504

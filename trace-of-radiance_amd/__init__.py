@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "tor_selftest_rng_host", "tor_version",
     "tor_last_render_timing", "tor_comm_unique_id", "tor_comm_init_rank", "tor_comm_destroy", "tor_render_gather_device",
     "tor_context_scene_counters", "tor_render_ptr", "tor_last_pixel_cost", "tor_last_note", "tor_last_handoff_counters",
-    "tor_selftest_screen2_host", "tor_debug_screen2_scene", "tor_knob_count", "tor_knob_info", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
+    "tor_selftest_screen2_host", "tor_debug_screen2_scene", "tor_debug_layout_segments", "tor_knob_count", "tor_knob_info", "tor_last_gather_info", "tor_last_device_kernel_ms", "tor_comm_abort", "tor_comm_count", "tor_context_handoff_stalled",
 ]
 
 _lib = None
@@ -244,6 +244,7 @@ def lib():
     L.tor_selftest_slab32_host.argtypes = [C.c_int64] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int32)] * 2
     L.tor_debug_filter32_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8)]
     L.tor_debug_screen2_scene.argtypes = [HittableList, C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int8), C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.c_int64]
+    L.tor_debug_layout_segments.argtypes = [HittableList, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]
     L.tor_selftest_math_device.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_int32]
     L.tor_selftest_math_host.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_int64]
     L.tor_selftest_rng_host.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -768,6 +769,14 @@ def debug_filter32_scene(world: HittableList, o, d, time):
     _check(lib().tor_debug_filter32_scene(world, len(time), o.ctypes.data_as(P), d.ctypes.data_as(P), time.ctypes.data_as(P),
                                           keep.ctypes.data_as(C.POINTER(C.c_int8))))
     return keep
+
+
+def debug_layout_segments(world: HittableList, max_segs: int = 64):
+    """[(xkind, objects, slots, first slot), ...]: the float64 layout's segments in the order the kernel walks them (host only)."""
+    out = np.zeros((max_segs, 4), dtype=np.int32)
+    n = C.c_int64(0)
+    _check(lib().tor_debug_layout_segments(world, out.ctypes.data_as(C.POINTER(C.c_int32)), max_segs, C.byref(n)))
+    return [tuple(int(v) for v in row) for row in out[:min(int(n.value), max_segs)]]
 
 
 def debug_screen2_scene(world: HittableList, o, d, time, max_segs: int = 0):

@@ -1518,6 +1518,26 @@ int tor_debug_filter32_scene(TorHittableList world, int64_t n_rays, const double
 // by the plane screen, 1 dropped by stage two, 2 a candidate of the exact test, 3 the object is on a segment without a table (a
 // time group whose fraction is never finite).  kind_out[object] (nullable) = its segment's xkind (0, 10-14);
 // pays_out[ray * n_segs_out + segment] (nullable, with n_segs_out) = plane_pays' vote of that ray.  No device needed.
+int tor_debug_layout_segments(TorHittableList world, int32_t* out, int64_t max_segs, int64_t* n_segs_out) {
+  if (world.len < 0 || (world.len > 0 && !world.objects) || max_segs < 0 || (max_segs > 0 && !out) || !n_segs_out)
+    return fail(TOR_ERR_INVALID_ARGUMENT, "tor_debug_layout_segments: bad argument");
+  std::vector<int64_t> ids((size_t)world.len);
+  for (int64_t i = 0; i < world.len; ++i) ids[(size_t)i] = i;
+  tor::HostLayout lay;
+  std::string err;
+  if (!tor::build_layout(world.objects, ids, lay, err, nullptr)) return fail(TOR_ERR_INVALID_ARGUMENT, err);
+  *n_segs_out = lay.n_segs;
+  for (int s = 0; s < lay.n_segs && s < max_segs; ++s) {
+    const double* sg = &lay.segs[8 * (size_t)s];
+    const int count = (int)sg[2] & 0xffffff, real = count - ((int)sg[2] >> 24);
+    out[4 * s + 0] = (int32_t)lay.xsegs[8 * (size_t)s];
+    out[4 * s + 1] = real;
+    out[4 * s + 2] = count;
+    out[4 * s + 3] = (int32_t)sg[3] * (int32_t)tor::kPad;
+  }
+  return TOR_OK;
+}
+
 int tor_debug_screen2_scene(TorHittableList world, int64_t n_rays, const double* o, const double* d, const double* time, int8_t* keep,
                             int32_t* kind_out, int8_t* pays_out, int64_t n_segs_out) {
   if (world.len < 0 || (world.len > 0 && !world.objects) || n_rays < 0 || !o || !d || !time || !keep)
