@@ -371,10 +371,12 @@ TOR_API int tor_kernel_ms_mean(TorContext* ctx, int32_t last_n, float* mean_ms_o
 typedef struct TorStats {
   uint64_t hit_queries;       /* world.hit() calls (hittables_lists.nim:48-55)          */
   uint64_t object_tests;      /* hit_queries * n_objects                                 */
-  uint64_t candidates;        /* objects that survived the discriminant filter           */
+  uint64_t candidates;        /* objects that went past the wave-uniform object loop: block_tests + exact_tests */
   uint64_t wave_iterations;   /* bounce-loop trips summed over waves                     */
   uint64_t lane_slots;        /* 64 * wave_iterations                                    */
   uint64_t samples;           /* pixel-samples traced                                    */
+  uint64_t block_tests;       /* TOR_ACCEL_BLOCKS | TOR_ACCEL_F32: objects the float32 filter looked at in the blocks a ray entered (8 per block) */
+  uint64_t exact_tests;       /* candidates - block_tests: objects that reached the reference's own test (spheres.nim:28-49) */
 } TorStats;
 TOR_API int tor_context_set_stats(TorContext* ctx, int32_t enable);
 TOR_API int tor_last_stats(TorContext* ctx, TorStats* out);

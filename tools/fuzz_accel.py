@@ -3,8 +3,13 @@ WITHOUT its conservative FMA screen (TOR_SCREEN=0, DESIGN 4.2: no plane screen, 
 discriminant for every object) and the brute force with stage one of the screen FORCED onto every segment that carries a plane
 table (TOR_PLANE=2: no gate) -- against the float64 brute-force canvas (default: the host's gate and the waves' votes decide per
 segment), bit for bit.
-Usage: python tools/fuzz_accel.py [seconds] [seed] [heights]     heights: mixed (default: half of the scenes rest their spheres on
-1-4 common heights) | none (every sphere at its own height: no common-height segment anywhere -- the round-5 record)"""
+Usage: python tools/fuzz_accel.py [seconds] [seed] [heights] [--oracle K]
+    heights: mixed (default: half of the scenes rest their spheres on 1-4 common heights) | none (every sphere at its own height: no
+             common-height segment anywhere -- the round-5 record)
+    --oracle K (round 6): every K-th scene is ALSO rendered by the CPU oracle (oracle/tor_oracle.c: the restatement of the reference,
+             PORTABLE math, the accumulation of the stream mode) in both stream modes and the GPU brute force must equal it bit for bit --
+             a GPU-vs-GPU diff cannot see a defect in what every loop family shares (layout, padding, segment order); the oracle
+             walks the caller's list in the caller's order like hittables_lists.nim:48-55.  (The oracle is the checker here, as in tests/.)"""
 import importlib
 import os
 import sys
@@ -63,10 +68,21 @@ def random_scene(rng):
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    argv = list(sys.argv[1:])
+    oracle_every = 0
+    if "--oracle" in argv:
+        k = argv.index("--oracle")
+        oracle_every = int(argv[k + 1])
+        del argv[k:k + 2]
+    budget = float(argv[0]) if len(argv) > 0 else 120.0
+    rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 12345)
     global HEIGHTS
-    HEIGHTS = sys.argv[3] if len(sys.argv) > 3 else "mixed"
+    HEIGHTS = argv[2] if len(argv) > 2 else "mixed"
+    O = None
+    if oracle_every > 0:
+        from oracle import oracle as O   # the checker (test infrastructure), never the product
+        O.build()
+    n_oracle = 0
     os.environ["TOR_SCREEN"] = "0"
     unscreened = tor.Context(0)      # (the knob is read when a context is made; tor.render() below uses the default context)
     os.environ.pop("TOR_SCREEN", None)
@@ -88,6 +104,15 @@ def main():
                 tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=seeding, accel=accel, pixel_kernel=1))
                 canv.append(cv.pixels.copy())
                 n_renders += 1
+            if O is not None and n_scenes % oracle_every == 0:
+                # the arbiter: the reference's algorithm restated on the CPU, on the same list, camera and streams
+                ocam = np.frombuffer(bytes(cam), dtype=np.float64).copy()   # TorCamera = 24 float64 in cameras.nim's field order
+                want = O.render(h, w, spp, ocam, recs, max_depth=depth, seeding=seeding, math=O.MATH_PORTABLE, accum=seeding).pixels
+                n_oracle += 1
+                if not np.array_equal(canv[0], want, equal_nan=True):
+                    bad += 1
+                    print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} GPU brute force vs ORACLE: "
+                          f"{int((canv[0] != want).sum())} values differ, max {np.nanmax(np.abs(canv[0] - want)):.3e}", flush=True)
             # the same brute force without the FMA screen: every object through the reference's unfused discriminant
             unscreened.upload(scene.list())
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
@@ -120,7 +145,8 @@ def main():
                     print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} accel {accel}: "
                           f"{int((canv[0] != canv[accel]).sum())} values differ", flush=True)
         n_scenes += 1
-    print(f"fuzz (heights: {HEIGHTS}): {n_scenes} scenes, {n_renders} renders, {bad} mismatches in {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz (heights: {HEIGHTS}): {n_scenes} scenes, {n_renders} renders, {n_oracle} of them checked against the CPU oracle "
+          f"(every {oracle_every or '-'}th scene, both stream modes), {bad} mismatches in {time.time() - t0:.0f} s", flush=True)
     sys.exit(1 if bad else 0)
 
 

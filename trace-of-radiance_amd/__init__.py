@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -115,7 +116,8 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("hit_queries", C.c_uint64), ("object_tests", C.c_uint64), ("candidates", C.c_uint64),
-                ("wave_iterations", C.c_uint64), ("lane_slots", C.c_uint64), ("samples", C.c_uint64)]
+                ("wave_iterations", C.c_uint64), ("lane_slots", C.c_uint64), ("samples", C.c_uint64),
+                ("block_tests", C.c_uint64), ("exact_tests", C.c_uint64)]
 
 
 assert C.sizeof(Vec3) == 24 and C.sizeof(Material) == 40 and C.sizeof(Sphere) == 72
@@ -187,7 +189,10 @@ def lib():
             pass
     # (harness-side A/B switch of the tools: TOR_AB_LIB = another build of THIS library -- e.g. last round's kernels -- to measure
     # against in the same gpurun call; never a fallback: unset, the in-tree library above is the only one there is)
-    L = C.CDLL(os.environ.get("TOR_AB_LIB") or LIB_PATH)
+    ab = os.environ.get("TOR_AB_LIB")
+    if ab:  # never silent: every consumer of this process measures / validates ANOTHER binary
+        print(f"trace-of-radiance_amd: TOR_AB_LIB set -- loading {ab} instead of the in-tree library", file=sys.stderr, flush=True)
+    L = C.CDLL(ab or LIB_PATH)
     dp = C.POINTER(C.c_double)
     L.tor_last_error.restype = C.c_char_p
     L.tor_version.restype = C.c_char_p

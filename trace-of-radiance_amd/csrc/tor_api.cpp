@@ -341,7 +341,6 @@ int tor_context_create(int32_t device, TorContext** out) {
   if (const char* c = tor::knob("TOR_COOP_MAX_PIXELS")) ctx->coop_max_pixels = std::atoll(c);
   if (const char* c = tor::knob("TOR_HOT_FRAC")) ctx->hot_frac = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_PRIO_SHIFT")) ctx->prio_shift = std::atoi(c);
-  if (const char* c = tor::knob("TOR_SPLIT_FRAC")) ctx->split_frac = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_MIGRATE")) ctx->mig_mode = std::atoi(c);
   if (const char* c = tor::knob("TOR_SRV_FRAC")) ctx->srv_frac = (float)std::atof(c);
   if (const char* c = tor::knob("TOR_SRV_PATIENCE_US")) ctx->srv_patience_us = std::atoi(c);
@@ -1161,7 +1160,7 @@ int tor_last_stats(TorContext* ctx, TorStats* out) {
   if (!ctx->collect_stats) return fail(TOR_ERR_INVALID_ARGUMENT, "tor_last_stats: stats not enabled");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipDeviceSynchronize());
-  unsigned long long h[8];
+  unsigned long long h[12];
   HIP_TRY(hipMemcpy(h, (unsigned long long*)ctx->counters.ptr + (size_t)ctx->last_slot * TorContext::kSlotWords, sizeof h, hipMemcpyDeviceToHost));
   out->hit_queries = h[1];
   out->object_tests = h[1] * (uint64_t)ctx->n_objects;
@@ -1169,6 +1168,10 @@ int tor_last_stats(TorContext* ctx, TorStats* out) {
   out->wave_iterations = h[3];
   out->lane_slots = h[3] * 64;
   out->samples = h[4];
+  // word 11 (= KParams.stats + 10): the cooperative variants count the objects their float32 block filter looked at apart from the
+  // survivors that reach the exact float64 test; the per-lane block expansion (TOR_ACCEL_BLOCKS alone) runs the exact test on all 8
+  out->block_tests = h[11];
+  out->exact_tests = h[2] - h[11];
   return TOR_OK;
 }
 

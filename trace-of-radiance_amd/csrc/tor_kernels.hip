@@ -134,7 +134,13 @@ constexpr int kAccSlots = 16;  // per-wave LDS pixel-accumulator cache (TOR_SEED
 static_assert(kBlock == kPad, "hot-record padding must equal the candidate block size");
 
 // LDS per wave: queue (queue_cap*64 u32) + accumulator cache (kAccSlots * (3 f64 + tag)) + debug counters
+#ifdef TOR_FINE_PROBE
+// tools/fine_probe.py's build (make fine): eight more cycle counters inside the object loop and the pooled resolve of the cooperative
+// variants; they leave the kernel through the wave log's wall-clock words (which that build therefore does not report)
+constexpr int kProfSlots = 24;
+#else
 constexpr int kProfSlots = 16;  // debug counters (u64, stats / wave log only): 5 section sums, trips, begin, last stamp, 4 statistics, 3 wave-log stamps
+#endif
 // cooperative resolve (F32 && BLOCKS variants): pair list and survivor list (64 carried over + 512 new per trip), the
 // per-ray closest hit {t bits, (original index, slot)}
 constexpr int kCoopList = 576;
@@ -344,8 +350,26 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   // loop, kept in LDS (lane 0) so that the counters cost no registers when they are off
   const bool prof = p.wave_log != nullptr;
   enum { kSecRefill = 0, kSecLoop, kSecResolve, kSecShade, kSecDeposit, kSecTrips, kSecBegin, kSecMark,
-         kStQueries, kStCand, kStIters, kStSamples, kLogStart, kLogExhausted, kLogItersAtExhaustion, kSecStage2 };
+         kStQueries, kStCand, kStIters, kStSamples, kLogStart, kLogExhausted, kLogItersAtExhaustion, kSecStage2,
+         // (TOR_FINE_PROBE builds only) the mark and seven interval sums: ray set-up, box loop, direct float32 segments, segment headers /
+         // loop control, list building (A), block expansion (B), exact tests (C)
+         kFineMark, kFineSetup, kFineBoxes, kFineF32, kFineHdr, kFineA, kFineB, kFineC };
+  // objects tested inside expanded blocks (TOR_ACCEL_BLOCKS; part of kStCand): shares the slot of stage two's cycle counter, which
+  // only the ARITH 2 variants -- brute-force layouts, no blocks -- use
+  constexpr int kStBlock = kSecStage2;
   static_assert(kSecStage2 < kProfSlots, "debug counters");
+#ifdef TOR_FINE_PROBE
+  static_assert(kFineC < kProfSlots, "debug counters");
+  int fine_state = kFineA;
+#define TOR_FINE(slot)                                            \
+  if (prof && lane == 0) {                                        \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_lds[slot] += now_ - prof_lds[kFineMark];                 \
+    prof_lds[kFineMark] = now_;                                   \
+  }
+#else
+#define TOR_FINE(slot)
+#endif
   if ((stats_on || prof) && lane == 0) {
     for (int k = 0; k < kProfSlots; ++k) prof_lds[k] = 0;
     prof_lds[kSecBegin] = prof_lds[kSecMark] = __builtin_readcyclecounter();
@@ -372,6 +396,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   for (; lane_role;) {
 #include "kernel/integrate_refill.inc"
     TOR_SEC(kSecRefill)
+    TOR_FINE(kFineMark)
     const unsigned long long active_mask = ballot64(active);
     if (active_mask == 0) {
       if (exhausted) break;
@@ -484,6 +509,7 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       unsigned long long fc_t0 = 0x7ff8dead00000001ull, fc_dt = 0x7ff8dead00000002ull;  // (NaN patterns no object carries)
       unsigned mw = 0;      // the running mask
       int w_base = 0;       // first word of the current pass (words = slots / 32 over the whole sorted list)
+      TOR_FINE(kFineSetup)
       for (;;) {
         unsigned qn = 0;
         bool full = false;
@@ -610,12 +636,14 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
         }  // if (active)
 
         TOR_SEC(kSecLoop)
+        TOR_FINE(kFineHdr)
         if constexpr (kCoop) {
 #include "kernel/integrate_resolve_coop.inc"
         } else if (active) {
 #include "kernel/integrate_resolve_lane.inc"
         }  // per-lane resolve
         TOR_SEC(kSecResolve)
+        TOR_FINE(kFineA)
         if (ballot64(active && full) == 0) break;
         if (kWords) w_base += kQCap;
       }
@@ -676,15 +704,23 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
       // six 21-bit fields in units of 4096 shader cycles: refill+camera, object loop, exact resolve | shade, deposit, total
       const unsigned long long total = __builtin_readcyclecounter() - prof_lds[kSecBegin];
       auto f21 = [](unsigned long long c) { c >>= 12; return c > 0x1fffffull ? 0x1fffffull : c; };
-      w[2] = (prof_lds[kStIters] & 0xffffffffffull) | (f21(prof_lds[kSecStage2]) << 43);  // bounce iterations | stage two of the plane-screened segments (part of the object loop's field)
+      w[2] = (prof_lds[kStIters] & 0xffffffffffull) | (ARITH == 2 ? f21(prof_lds[kSecStage2]) << 43 : 0ull);  // bounce iterations | stage two of the plane-screened segments (part of the object loop's field)
       w[6] = f21(prof_lds[kSecRefill]) | (f21(prof_lds[kSecLoop]) << 21) | (f21(prof_lds[kSecResolve]) << 42);
       w[7] = f21(prof_lds[kSecShade]) | (f21(prof_lds[kSecDeposit]) << 21) | (f21(total) << 42);
+#ifdef TOR_FINE_PROBE
+      auto f32u = [](unsigned long long c) { c >>= 8; return c > 0xffffffffull ? 0xffffffffull : c; };  // units of 256 shader cycles
+      w[0] = f32u(prof_lds[kFineSetup]) | (f32u(prof_lds[kFineBoxes]) << 32);
+      w[1] = f32u(prof_lds[kFineF32]) | (f32u(prof_lds[kFineHdr]) << 32);
+      w[4] = f32u(prof_lds[kFineA]) | (f32u(prof_lds[kFineB]) << 32);
+      w[5] = f32u(prof_lds[kFineC]) | (prof_lds[kSecTrips] << 32);
+#endif
     }
     if (lane == 0) {
       atomicAdd(p.stats + 0, prof_lds[kStQueries]);
       atomicAdd(p.stats + 1, prof_lds[kStCand]);
       atomicAdd(p.stats + 2, prof_lds[kStIters]);
       atomicAdd(p.stats + 3, prof_lds[kStSamples]);
+      if (ARITH != 2) atomicAdd(p.stats + 10, prof_lds[kStBlock]);
     }
   }
 }

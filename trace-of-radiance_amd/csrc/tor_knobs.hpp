@@ -34,6 +34,7 @@ constexpr Knob kKnobs[] = {
     // ---- launch shape ----
     {"TOR_BLOCKS_PER_CU", "3", "1..8", "context", "workgroups per CU of integrate_kernel (all modes)"},
     {"TOR_WAVES_PER_SIMD", "(from the launch shape)", "2 | 3", "context", "force the register-budget variant of integrate_kernel (256 / 168 VGPRs)"},
+    {"TOR_ACCEL_ORDER", "sah", "sah | morton", "upload", "order of the objects behind TOR_ACCEL_BLOCKS' boxes: top-down surface-area build (round 6) or the Morton curve of rounds 1-5 (A/B; same canvas)"},
     {"TOR_STAGE_LDS", "(no cap)", "bytes, 0 = off", "call", "cap of the LDS staging of block records / boxes (TOR_ACCEL_BLOCKS)"},
     {"TOR_SCREEN", "1", "0 | 1", "context", "0: strict brute-force launches evaluate the reference's unfused discriminant for every object instead of the conservative FMA screen (same canvas)"},
     {"TOR_PLANE", "1", "0 | 1 | 2", "context", "stage one of the FMA screen (the 4-instruction plane screen in front of the segment's wave-uniform test, per-lane stage two on what it keeps): 0 off, 1 on the segments where it pays (default), 2 on every segment (same candidates, same canvas)"},
@@ -42,7 +43,6 @@ constexpr Knob kKnobs[] = {
     {"TOR_LPT_MIN_SPP", "32", ">= 0", "context", "cost probe + chain-length-ordered tile schedule from this many spp on; 0 = never"},
     {"TOR_HOT_FRAC", "0.4", ">= 0", "context", "a pixel chain is HOT (arbiter priority 3) from this share of an average wave's iterations; 0 = off"},
     {"TOR_PRIO_SHIFT", "16", "0..31", "context", "arbiter-priority rotation period, log2 shader-clock ticks; 0 = off"},
-    {"TOR_SPLIT_FRAC", "(automatic)", "0..1", "context", "split mode: share of the probed cost that goes to the wave-per-pixel kernel; 0 = off"},
     // ---- TOR_SEED_PIXEL chain hand-off (DESIGN 4.7 (HISTORY 4.10)) ----
     {"TOR_MIGRATE", "1", "0 | 1", "context", "0: no chain hand-off (split mode / wave-per-pixel kernel instead)"},
     {"TOR_SRV_FRAC", "0.07", "0..1", "context", "share of the workgroups that start as servers when the frame can hold a chain above the threshold's floor"},

@@ -543,6 +543,9 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
 
 namespace {
 
+// scenes of more blocks than this get a second level of boxes (measured, round 2: 61 blocks are faster flat, 200 with two levels)
+constexpr size_t kTwoLevelMinBlocks = 96;
+
 uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
   v &= 0x3ff;
   v = (v | (v << 16)) & 0x030000FF;
@@ -586,24 +589,97 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   if (spatial.size() < 32) return;
   std::string err;
   if (!build_layout(objs, always, out.always, err, f32)) return;
-  // Morton order over the spatial objects' (start) centres
-  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  auto c0 = [&](int64_t i, int a) {
-    const TorVec3& c = objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.center : objs[i].u.moving_sphere.center0;
-    return a == 0 ? c.x : (a == 1 ? c.y : c.z);
-  };
-  for (int64_t i : spatial)
-    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c0(i, a)); hi[a] = std::max(hi[a], c0(i, a)); }
-  double ext = 1e-300;
-  for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+  // Order of the spatial objects (closest hit is order independent -- hittables_lists.nim:48-55 -- so the order is free, and
+  // everything downstream only assumes "blocks = 8 consecutive objects, super boxes = 8 consecutive blocks").
+  // Round 6: a top-down build by the surface-area heuristic instead of the Morton curve of rounds 1-5.  Every node sorts its
+  // objects along each axis, prices every split position that keeps the children whole -- multiples of 8 objects, of 64 (one super
+  // box) above that when the scene will get a second level -- by area(left) x count(left) + area(right) x count(right) over
+  // the hulls of the spheres' whole motion, and takes the cheapest.  Blocks cut from a Morton curve straddle the curve's
+  // jumps: on random_scene the summed area of the 61 block boxes falls from 2802 to 1467 and a ray enters ~0.6 x the blocks, on
+  // the 1601-sphere animation frames 23 034 -> 11 259 and ~0.5 x (both levels); the expansion work per query falls with it.
+  // TOR_ACCEL_ORDER=morton keeps the old order (A/B; same canvas either way).
   std::vector<std::pair<uint32_t, int64_t>> keyed;
   keyed.reserve(spatial.size());
-  for (int64_t i : spatial) {
-    uint32_t q[3];
-    for (int a = 0; a < 3; ++a) q[a] = (uint32_t)std::min(1023.0, std::max(0.0, (c0(i, a) - lo[a]) / ext * 1023.0));
-    keyed.push_back({spread10(q[0]) | (spread10(q[2]) << 1) | (spread10(q[1]) << 2), i});
+  const char* order_knob = knob("TOR_ACCEL_ORDER");
+  const bool use_morton = order_knob && std::strcmp(order_knob, "morton") == 0;
+  if (use_morton) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    auto c0 = [&](int64_t i, int a) {
+      const TorVec3& c = objs[i].kind == TOR_SPHERE ? objs[i].u.sphere.center : objs[i].u.moving_sphere.center0;
+      return a == 0 ? c.x : (a == 1 ? c.y : c.z);
+    };
+    for (int64_t i : spatial)
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c0(i, a)); hi[a] = std::max(hi[a], c0(i, a)); }
+    double ext = 1e-300;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+    for (int64_t i : spatial) {
+      uint32_t q[3];
+      for (int a = 0; a < 3; ++a) q[a] = (uint32_t)std::min(1023.0, std::max(0.0, (c0(i, a) - lo[a]) / ext * 1023.0));
+      keyed.push_back({spread10(q[0]) | (spread10(q[2]) << 1) | (spread10(q[1]) << 2), i});
+    }
+    std::stable_sort(keyed.begin(), keyed.end());
+  } else {
+    const size_t ns = spatial.size();
+    const bool second_level = (ns + kPad - 1) / kPad > kTwoLevelMinBlocks;
+    struct Hull { double lo[3], hi[3], mid[3]; };
+    std::vector<Hull> hull(ns);
+    for (size_t k = 0; k < ns; ++k) {
+      const TorHittableVariant& ob = objs[spatial[k]];
+      const bool mv = ob.kind == TOR_MOVING_SPHERE;
+      const TorVec3& a0 = mv ? ob.u.moving_sphere.center0 : ob.u.sphere.center;
+      const TorVec3& a1 = mv ? ob.u.moving_sphere.center1 : ob.u.sphere.center;
+      const double r = radii[(size_t)spatial[k]];
+      const double p0[3] = {a0.x, a0.y, a0.z}, p1[3] = {a1.x, a1.y, a1.z};
+      for (int a = 0; a < 3; ++a) {
+        hull[k].lo[a] = std::min(p0[a], p1[a]) - r;
+        hull[k].hi[a] = std::max(p0[a], p1[a]) + r;
+        hull[k].mid[a] = 0.5 * (p0[a] + p1[a]);
+      }
+    }
+    std::vector<uint32_t> ord(ns), best_ord, cand;
+    for (size_t k = 0; k < ns; ++k) ord[k] = (uint32_t)k;
+    std::vector<double> suffix;  // area of the hull of cand[pos..n)
+    auto half_area = [](const double lo[3], const double hi[3]) {
+      const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+      return dx * dy + dy * dz + dx * dz;
+    };
+    // (explicit stack: a degenerate scene must not recurse 10^5 deep)
+    std::vector<std::pair<size_t, size_t>> todo{{0, ns}};
+    while (!todo.empty()) {
+      const auto [b, e] = todo.back();
+      todo.pop_back();
+      const size_t n_here = e - b;
+      if (n_here <= (size_t)kPad) continue;
+      const size_t unit = (second_level && n_here > (size_t)(kPad * kPad)) ? (size_t)(kPad * kPad) : (size_t)kPad;
+      double best_cost = INFINITY;
+      size_t best_pos = (n_here / 2 + unit - 1) / unit * unit;  // fall-back (non-finite areas): the median, on x
+      if (best_pos >= n_here) best_pos = (n_here - 1) / unit * unit;
+      bool have = false;
+      for (int ax = 0; ax < 3; ++ax) {
+        cand.assign(ord.begin() + (long)b, ord.begin() + (long)e);
+        std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return hull[x].mid[ax] < hull[y].mid[ax]; });
+        suffix.assign(n_here + 1, 0.0);
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = n_here; k-- > 0;) {
+          for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], hull[cand[k]].lo[a]); hi[a] = std::max(hi[a], hull[cand[k]].hi[a]); }
+          suffix[k] = half_area(lo, hi);
+        }
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (size_t k = 0; k + 1 < n_here; ++k) {
+          for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], hull[cand[k]].lo[a]); hi[a] = std::max(hi[a], hull[cand[k]].hi[a]); }
+          const size_t pos = k + 1;
+          if (pos % unit != 0) continue;
+          const double cost = half_area(lo, hi) * (double)pos + suffix[pos] * (double)(n_here - pos);
+          if (cost < best_cost) { best_cost = cost; best_pos = pos; best_ord = cand; have = true; }
+        }
+        if (!have && ax == 0) best_ord = cand;
+      }
+      std::copy(best_ord.begin(), best_ord.end(), ord.begin() + (long)b);
+      todo.push_back({b + best_pos, e});
+      todo.push_back({b, b + best_pos});
+    }
+    for (size_t k = 0; k < ns; ++k) keyed.push_back({(uint32_t)k, spatial[ord[k]]});
   }
-  std::stable_sort(keyed.begin(), keyed.end());
   out.n_blocks = (keyed.size() + kPad - 1) / kPad;
   // box fan-out (tor_scene.hpp, tor_kernels.hpp kBoxFanout): 1.  Measured as a launch parameter in round 4 (commit c39354b,
   // profiles/r4_fanout_sweep.txt): halving the box tests does NOT pay -- random_scene 56.4 / 59.0 / 73.0 / 115.3 ms and the
@@ -658,7 +734,7 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
   // the super boxes (kind 4: first record n_bnd_p + 1 of the bounds array) and the lanes descend
   const size_t n_super = n_bnd_p / kPad;
   const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;
-  size_t two_level_min = 96;
+  const size_t two_level_min = kTwoLevelMinBlocks;
   out.two_level = out.n_boxes > two_level_min;  // measured: 61 blocks are faster flat (2125 vs 1725 Msamples/s), 200 blocks faster with two levels (1916 vs 1663)
   if (out.two_level)
     out.always.segs.insert(out.always.segs.end(), {4.0, (double)(n_bnd_p + 1), (double)n_super_p, 0.0, 0.0, 0.0, 0.0, 0.0});
