@@ -89,6 +89,7 @@ def lib(variant: str | None = None):
     L.oracle_rng_uniform_range.restype = C.c_double
     L.oracle_port_sincos.argtypes = [dp, dp, dp, C.c_int64]
     L.oracle_libm_sincos.argtypes = [dp, dp, dp, C.c_int64]
+    L.oracle_port_sincos_slow_dd.argtypes = [dp, dp, dp, dp, C.c_int64]
     L.oracle_port_pow5.argtypes = [dp, dp, C.c_int64]
     L.oracle_port_pow.argtypes = [dp, C.c_double, dp, C.c_int64]
     L.oracle_libm_pow.argtypes = [dp, C.c_double, dp, C.c_int64]

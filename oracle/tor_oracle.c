@@ -240,7 +240,11 @@ static const dd DD_LN2 = { 0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56 };
 /* sin and cos of a in [0, 8): the argument range the path produces is
  * [0, 2*pi) (sampling.nim:52).  Both results are the double nearest to the exact
  * value except with probability ~2^-17 per call. */
-static void port_sincos_slow(double a, double* s_out, double* c_out) {
+static void port_sincos_slow_dd(double a, double* s_out, double* c_out, double* lo_out);
+static void port_sincos_slow(double a, double* s_out, double* c_out) { port_sincos_slow_dd(a, s_out, c_out, NULL); }
+/* (lo_out, tests only: the low words of the two double-double results, {sin, cos}) */
+static void port_sincos_slow_dd(double a, double* s_out, double* c_out, double* lo_out) {
+  if (lo_out) lo_out[0] = lo_out[1] = 0.0;
   if (!(a >= 0.0 && a < 8.0)) { *s_out = sin(a); *c_out = cos(a); return; } /* off-path */
   int k = (int)(a * TWO_OVER_PI + 0.5);
   double fk = (double)k;
@@ -274,21 +278,49 @@ static void port_sincos_slow(double a, double* s_out, double* c_out) {
     case 2: *s_out = -S; *c_out = -C; break;
     default: *s_out = -C; *c_out = S; break;
   }
+  if (lo_out) {
+    switch (k & 3) {
+      case 0: lo_out[0] = sn.lo;  lo_out[1] = cs.lo;  break;
+      case 1: lo_out[0] = cs.lo;  lo_out[1] = -sn.lo; break;
+      case 2: lo_out[0] = -sn.lo; lo_out[1] = -cs.lo; break;
+      default: lo_out[0] = -cs.lo; lo_out[1] = sn.lo; break;
+    }
+  }
 }
 
 /* ---- sincos: fast path (round 5).  The double-double evaluation above costs ~290 float64 operations per call and the GPU runs it
  * on every bounce iteration of every wave (sampling.nim:51-55 through materials.nim:24-30).  The fast path gets the SAME doubles
  * -- both are the correctly rounded value -- from ~85 operations and PROVES it per call (Ziv's rounding test); a call whose test
- * fails (~1 in 600) takes the double-double path.  csrc/tor_math.hpp carries the same operations in the same order.
+ * fails (~1 in 300) takes the double-double path.  csrc/tor_math.hpp carries the same operations in the same order.
  *   a = j h + r, h = pi/128, |r| <= h/2 (+ one rounding of a * 128/pi); r = rh + rl to ~2^-125 (H1, H2 short: j * H1 and j * H2 are
  *     exact for j <= 256, a - j * H1 is exact by Sterbenz's lemma);
- *   sin r - r = rh z ps(z), cos r - 1 = -z/2 + ce, z = rh^2 (Taylor to r^9 / z^4: truncation < 2^-69 at |r| <= 0.0124);
+ *   sin r - r = rh z ps(z), cos r - 1 = -z/2 + ce, z = rh^2 (Taylor to r^9 / r^8);
  *   sin a = S (1 + (cos r - 1)) + C (r + (sin r - r)) with (S, C) = sin, cos(j h) from a table of double-doubles: the large terms
- *     S.hi, C.hi rh, S.hi (-z/2) enter exactly (two_prod, fast_two_sum), the rest in one correction of relative size < 2^-14
- *     whose roundings stay below 2^-66 of the result; cos a likewise with (C, -S).
- *   Rounding test: the result is h + corr with |error| < 2^-64 |h| (measured: < 2^-65.6 over 4e6 arguments against mpmath,
- *     tests/test_oracle_math.py); if h + (corr - 2^-64 |h|) and h + (corr + 2^-64 |h|) round to the same double, that double is
- *     the correctly rounded value. */
+ *     S.hi, C.hi rh, S.hi (-z/2) enter exactly (two_prod, fast_two_sum), the rest in one correction of relative size < 2^-14;
+ *     cos a likewise with (C, -S).
+ *   Rounding test: the result is h + corr, and if h + (corr - e) and h + (corr + e) round to the same double for an e that
+ *     bounds |h + corr - exact|, that double is the correctly rounded value.  e = 2^-63 |h| (round 6; 2^-64 before), four times
+ *     the bound below; it costs a fall-back rate of ~1 in 300 instead of 1 in 600.
+ *   Error budget of h + corr (sin side; cos is the same with the roles of S and C swapped), relative to |h|, rho = |r| <=
+ *     0.012273; the worst case is a zero crossing of the result (S ~ 0: |h| ~ |C| rho), elsewhere |h| >= 0.012 and every
+ *     term is smaller by rho / |h|; u = 2^-53:
+ *       reduction   r = rh + rl up to 256 x the tail of pi/128 behind H3 (2^-128) + the rounding of rl (u^2 rho): at j = 0
+ *                   a = r exactly, at j = 128, 256 |r| >= 2^-53 (pi is not a double), elsewhere |h| >= 0.012  -> < 2^-75
+ *       table       S, C to 2^-106 relative; sin(pi) = 0 and cos(pi / 2) = 0 are exact entries                  -> < 2^-99
+ *       truncation  sin r - r after r^9: rho^10 / 11!                                                            -> 2^-88.7
+ *                   cos r - 1 after r^8: rho^10 / 10! (times |S| / |h| <= 2)                                     -> 2^-84.3
+ *       sr          = (rh z) ps: roundings of z, of the three fma of ps, of rh z, of the product and the four rounded
+ *                   coefficients: 4.1 u |sr|, |sr| <= rho^3 / 6                                                  -> 2^-66.24
+ *       sr uses rh  d(sin r - r)/dr rl = (cos r - 1) rl, |rl| <= u rho: u rho^2 / 2                              -> 2^-66.70
+ *       t           = fl(rl + sr): u |t|                                                                         -> 2^-68.3
+ *       ce          ~3 u |ce|, |ce| <= rho^4 / 24 + u rho^2 = 2^-30, times |S| / |h| <= 2                        -> 2^-80
+ *       corr        the sum of the four exact low parts and Sl (1 + hz): each <= u max(|S|, |h|), three additions -> 2^-102
+ *                   fma(Cl, rh, .), fma(Sh, ce, .): u (2^-30 |S| + 2^-51 |h|)                                    -> 2^-82
+ *                   fma(Ch, t, .): u (rho^3 / 6 + ...)                                                           -> 2^-68.3
+ *       (second-order terms: u^2)                                                                                -> 2^-100
+ *     sum < 2^-64.9 |h|   (the worst measured over 1.95 M arguments incl. the table's nodes, the half-interval boundaries and
+ *     the neighbourhoods of pi / 2, pi, 3 pi / 2, 2 pi: 2^-65.6 -- tests/test_oracle_math.py checks EVERY argument against the
+ *     double-double evaluation, whose own error, < 2^-73, is checked against mpmath). */
 static const double SINCOS_TAB[257 * 4] = {
 #include "tor_sincos_table.inc"
 };
@@ -296,7 +328,7 @@ static const double SINCOS_TAB[257 * 4] = {
 #define SC_H1 0x1.921fb54000000p-6
 #define SC_H2 0x1.10b4611a62600p-36
 #define SC_H3 0x1.98a2e03707345p-83
-#define SC_EPS 0x1p-64
+#define SC_EPS 0x1p-63
 static inline int sc_ziv(double h, double corr, double* out) {
   const double e = fabs(h) * SC_EPS;
   const double r1 = h + (corr + e), r2 = h + (corr - e);
@@ -855,6 +887,8 @@ EXPORT double oracle_rng_uniform_range(uint64_t state[4], double lo, double hi) 
 EXPORT void oracle_port_sincos(const double* a, double* s, double* c, int64_t n) { for (int64_t i = 0; i < n; ++i) port_sincos(a[i], &s[i], &c[i]); }
 /* the double-double path alone, and the fast path alone with its verdict (tests) */
 EXPORT void oracle_port_sincos_slow(const double* a, double* s, double* c, int64_t n) { for (int64_t i = 0; i < n; ++i) port_sincos_slow(a[i], &s[i], &c[i]); }
+/* the double-double results of the slow path: lo[2 i], lo[2 i + 1] = the low words of sin, cos */
+EXPORT void oracle_port_sincos_slow_dd(const double* a, double* s, double* c, double* lo, int64_t n) { for (int64_t i = 0; i < n; ++i) port_sincos_slow_dd(a[i], &s[i], &c[i], lo + 2 * i); }
 EXPORT void oracle_port_sincos_fast(const double* a, double* s, double* c, int32_t* ok, double* parts, int64_t n) {
   for (int64_t i = 0; i < n; ++i) ok[i] = port_sincos_fast_parts(a[i], &s[i], &c[i], parts ? parts + 4 * i : NULL);
 }

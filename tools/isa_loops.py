@@ -1,7 +1,7 @@
 """Static instruction mix of every loop of one integrate_kernel variant in the generated ISA (make -C trace-of-radiance_amd/csrc asm).
 usage: python tools/isa_loops.py [substring of the mangled name, default the metric's kernel Li1ELi2ELi3ELi0ELi0E] [--dump A B]"""
 import os, re, sys
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trace-of-radiance_amd", "lib", "asm", "tor_kernels.s")
+path = os.environ.get("TOR_ASM") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trace-of-radiance_amd", "lib", "asm", "tor_kernels.s")
 want = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "Li1ELi2ELi3ELi0ELi0E"
 text = open(path).read().split("\n")
 i0 = next(i for i, l in enumerate(text) if re.match(r"^_ZN3tor16integrate_kernel\w*:", l) and want in l)

@@ -2,7 +2,7 @@
 spill stores / loads in total and inside loops (a store inside the bounce loop is HBM write traffic on every iteration).
 usage: python tools/isa_spills.py [substring of the mangled kernel name]"""
 import os, re, sys
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trace-of-radiance_amd", "lib", "asm", "tor_kernels.s")
+path = os.environ.get("TOR_ASM") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trace-of-radiance_amd", "lib", "asm", "tor_kernels.s")
 want = sys.argv[1] if len(sys.argv) > 1 else "integrate_kernel"
 text = open(path).read().split("\n")
 starts = [(i, m.group(1)) for i, l in enumerate(text) if (m := re.match(r"^(_ZN3tor\w+):", l))]
