@@ -161,8 +161,17 @@ def test_handoff_stall_escape_flags_the_frame_and_the_blocking_entry_points_rend
             for _ in range(4):
                 buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
                 ctx.render_device(cam, h, w, spp, 2.2, 50, opt, buf.data_ptr(), s)
+                # (round 6) tor_last_kernel_ms itself reports the flagged frame: TOR_ERR_INCOMPLETE with *ms_out filled --
+                # through the bare C ABI, and through the wrapper (which keeps the timing and sets last_incomplete instead of raising)
+                import ctypes as C
+                ms, nsamp = C.c_float(-1.0), C.c_int64(0)
+                rc = tor.lib().tor_last_kernel_ms(ctx._h, C.byref(ms), C.byref(nsamp))
                 stalled, _ = ctx.handoff_stalled()
+                assert rc == (tor.ERR_INCOMPLETE if stalled else tor.OK) and ms.value > 0.0 and nsamp.value == h * w * spp
+                t_ms, _ = ctx.last_kernel_ms()
+                assert t_ms == ms.value and ctx.last_incomplete == stalled
                 if stalled:
+                    assert "INCOMPLETE" in tor.lib().tor_last_error().decode()
                     seen += 1
                 else:
                     assert torch.equal(buf, good)   # a frame that was not flagged is complete

@@ -192,22 +192,26 @@ def test_non_finite_ray_time_hits_statics_only(tor, oracle, ref_scene):
     reference's moving spheres get non-finite centres and can never be hit, its static spheres are hit as ever -- and rays
     scattered by metal / glass carry time 0 again (rays.nim:19).  Round 5 put random_scene's resting statics into the resting
     movers' segment (dc = 0): the screened loop, the wave-uniform loops and the unscreened loop must still find them at a
-    non-finite time fraction (integrate_loop_f64_movers.inc; tor_screen.hpp: a wild ray keeps everything).  == the oracle."""
+    non-finite time fraction (integrate_loop_f64_movers.inc; tor_screen.hpp: a wild ray keeps everything).  == the oracle.
+    Round 6: ... and at a FINITE time fraction whose square overflows (shutter_close = 1e155: f^2 = inf met the resting
+    statics' dcy = 0 as NaN in the second form's chain and the screen dropped them; |f| |dc| stays far below the wild limit because
+    random_scene's movers travel at most 0.5)."""
     import torch
     objs, _ = ref_scene
     scene = tor.random_scene(0xFACADE)
-    cam = tor.camera(shutter_open=0.0, shutter_close=float("inf"))
-    ocam = oracle.camera(shutter_open=0.0, shutter_close=float("inf"))
     h, w, spp = 54, 96, 8
-    for seeding in (0, 1):
-        want = oracle.render(h, w, spp, ocam, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels
-        assert np.isfinite(want).all() and float(want.sum()) > 0.0
-        for env in ({}, {"TOR_PLANE": "0"}, {"TOR_PLANE": "2"}, {"TOR_SCREEN": "0"}):
-            got, _ = _render_with_env(tor, scene, cam, h, w, spp, env, seeding=seeding, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE)
-            _exact(got.cpu().numpy(), want)
-        for accel in (1, 2, 3):
-            got, _ = _render_with_env(tor, scene, cam, h, w, spp, {}, seeding=seeding, accel=accel, pixel_kernel=tor.PIXEL_KERNEL_LANE)
-            _exact(got.cpu().numpy(), want)
+    for close in (float("inf"), 1e155, 3e154):
+      cam = tor.camera(shutter_open=0.0, shutter_close=close)
+      ocam = oracle.camera(shutter_open=0.0, shutter_close=close)
+      for seeding in (0, 1):
+          want = oracle.render(h, w, spp, ocam, objs, seeding=seeding, math=1, arith=0, accum=seeding).pixels
+          assert np.isfinite(want).all() and float(want.sum()) > 0.0
+          for env in ({}, {"TOR_PLANE": "0"}, {"TOR_PLANE": "2"}, {"TOR_SCREEN": "0"}):
+              got, _ = _render_with_env(tor, scene, cam, h, w, spp, env, seeding=seeding, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+              _exact(got.cpu().numpy(), want)
+          for accel in (1, 2, 3):
+              got, _ = _render_with_env(tor, scene, cam, h, w, spp, {}, seeding=seeding, accel=accel, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+              _exact(got.cpu().numpy(), want)
 
 
 def test_fused_arithmetic_is_refused_with_the_reason(tor):

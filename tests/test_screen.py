@@ -326,3 +326,27 @@ def test_layout_segments_largest_first_and_tails_padded_to_words(tor):
     # padding must not cost a pass: 9 segments of 50 are 504 slots in blocks, 576 in words -> stay in blocks
     segs = tor.debug_layout_segments(scene([50] * 9))
     assert all(s[2] == 56 for s in segs) and sum(s[2] for s in segs) == 504
+
+
+def test_resting_static_in_a_mover_segment_at_an_overflowing_time_fraction(tor):
+    """statics that rest at the common height of a segment of movers along y join it with dcy = 0.  A finite time
+    fraction whose SQUARE overflows (|f| > 1.3e154: shutter_close ~ 1e155) made f2n = sigma^2 f^2 = inf meet dcy = 0 as NaN in
+    screen2_movy_y, and the NaN's clear sign bit dropped a sphere the reference hits (travel |f| stays small: B is not wild).
+    The ray is wild for such an f now -- it keeps everything.  (This host build cannot fail on the old code: x86's default NaN has
+    its sign bit SET and happened to read as "keep", gfx950's is positive and read as "drop" -- the test that fails without the fix
+    is tests/test_gpu_round5.py::test_non_finite_ray_time_hits_statics_only with shutter_close = 1e155; this one pins the host side.)"""
+    rng = np.random.default_rng(77)
+    n = 20000
+    c0 = rng.uniform(-10, 10, size=(n, 3))
+    r = rng.uniform(0.1, 0.5, n)
+    o = rng.uniform(-15, 15, size=(n, 3))
+    target = c0 + rng.normal(size=(n, 3)) * (0.6 * r)[:, None]      # most rays hit
+    d = target - o
+    dc = np.zeros((n, 3))
+    moving = np.ones(n, dtype=np.int32)
+    for fval in (1e155, -3e154, 1.4e154, 1.2e154, 1e300):
+        f = np.full(n, fval)
+        keep, need = tor.selftest_screen2(o, d, c0, dc, moving, f, r * r, 0)
+        assert np.count_nonzero(need) > n // 2
+        missed = np.flatnonzero((need != 0) & (keep == 0))
+        assert missed.size == 0, (fval, missed[:5])

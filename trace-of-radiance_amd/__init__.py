@@ -33,6 +33,8 @@ ARITH_STRICT, ARITH_FUSED = 0, 1   # (ARITH_FUSED: removed in round 5; the libra
 ACCEL_NONE, ACCEL_BLOCKS, ACCEL_F32 = 0, 1, 2
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 PIXEL_KERNEL_AUTO, PIXEL_KERNEL_LANE, PIXEL_KERNEL_WAVE = 0, 1, 2
+# return codes (include/tor_render.h)
+OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_INCOMPLETE = 0, -1, -2, -3, -4, -5
 MAX_DEVICES = 16
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SPHERE, MOVING_SPHERE = 0, 1
@@ -552,6 +554,7 @@ class Context:
 
     def __init__(self, device: int = -1):
         self._h = C.c_void_p()
+        self.last_incomplete = False   # set by last_kernel_ms(): the last launch's hand-off stalled, its frame is not whole
         _check(lib().tor_context_create(device, C.byref(self._h)))
 
     def close(self):
@@ -635,9 +638,14 @@ class Context:
                                               C.byref(options), root, C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)))
 
     def last_kernel_ms(self):
+        """(kernel ms by HIP events, pixel-samples traced) of the last launch.  TOR_ERR_INCOMPLETE -- the launch's chain hand-off
+        stalled and flagged the frame -- does not raise: the timing is valid, `self.last_incomplete` says the frame is not."""
         ms = C.c_float(0)
         n = C.c_int64(0)
-        _check(lib().tor_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        rc = lib().tor_last_kernel_ms(self._h, C.byref(ms), C.byref(n))
+        self.last_incomplete = (rc == ERR_INCOMPLETE)
+        if rc != ERR_INCOMPLETE:
+            _check(rc)
         return float(ms.value), int(n.value)
 
     def kernel_ms_mean(self, last_n: int):

@@ -172,7 +172,11 @@ std::mutex g_comm_mutex;
 std::map<std::vector<int>, std::vector<ncclComm_t>> g_single_process_comms;  // per device list (ncclCommInitAll)
 struct CommSetup;
 std::map<std::vector<int>, std::shared_ptr<CommSetup>> g_comm_pending;       // creations in flight (helper threads), guarded by g_comm_mutex
-std::set<std::vector<int>> g_comm_timed_out;                                  // lists whose creation passed its deadline once
+// lists whose creation passed its deadline, and when: such a list is not tried again for kCommRetryAfterS seconds (a hung
+// creation leaves a helper thread behind per attempt), then it gets another chance (one transient time-out used to
+// disable the RCCL leg for the list for the rest of the process)
+std::map<std::vector<int>, std::chrono::steady_clock::time_point> g_comm_timed_out;
+constexpr int kCommRetryAfterS = 300;
 
 int shard_max_rows(int32_t nrows, int32_t row_tile, int32_t count) {
   int m = 0;
@@ -449,7 +453,17 @@ void comm_setup_body(std::shared_ptr<CommSetup> st) {
         cc = nullptr;
       }
   };
-  if (st->abandoned.load()) { drop(); return; }
+  // (an abandoned creation still marks the set-up done and wakes everybody: a second caller that joined the same pending set-up
+  // must not sit out its own full deadline for a helper thread that has already left -- ADVICE r5)
+  auto leave_abandoned = [&]() {
+    drop();
+    std::lock_guard<std::mutex> lock(st->m);
+    st->rc = TOR_ERR_HIP;
+    st->err = "RCCL: communicator creation was abandoned by the caller that started it (deadline passed)";
+    st->done = true;
+    st->cv.notify_all();
+  };
+  if (st->abandoned.load()) { leave_abandoned(); return; }
   // self-check: device k sends kCheck bytes of value (k * 37 + i) & 0xff through the very same grouped send/recv code, on
   // streams of its own
   constexpr size_t kCheck = 4096;
@@ -503,6 +517,10 @@ void comm_setup_body(std::shared_ptr<CommSetup> st) {
   std::lock_guard<std::mutex> lock(st->m);
   if (st->abandoned.load()) {  // (the flag is set under st->m: checked here, nothing can be published to a caller that has left)
     drop();
+    st->rc = TOR_ERR_HIP;
+    st->err = "RCCL: communicator creation was abandoned by the caller that started it (deadline passed)";
+    st->done = true;
+    st->cv.notify_all();
     return;
   }
   st->rc = check;
@@ -540,9 +558,12 @@ int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
       std::lock_guard<std::mutex> lock(g_comm_mutex);
       auto it = g_single_process_comms.find(j.key);
       if (it != g_single_process_comms.end()) comms = &it->second;
-      else if (g_comm_timed_out.count(j.key))
-        return fail(TOR_ERR_HIP, "RCCL: communicator creation for this device list timed out earlier in this process; not tried again");
+      else if (g_comm_timed_out.count(j.key) &&
+               std::chrono::steady_clock::now() - g_comm_timed_out[j.key] < std::chrono::seconds(kCommRetryAfterS))
+        return fail(TOR_ERR_HIP, "RCCL: communicator creation for this device list timed out less than " + std::to_string(kCommRetryAfterS) +
+                                     " s ago in this process; not tried again yet");
       else {
+        g_comm_timed_out.erase(j.key);
         auto pend = g_comm_pending.find(j.key);
         if (pend != g_comm_pending.end()) st = pend->second;
         else {
@@ -560,12 +581,19 @@ int gather_rccl(const GatherJob& j, const FaultInjection& fault) {
       {
         std::unique_lock<std::mutex> wait_lock(st->m);
         finished = st->cv.wait_for(wait_lock, std::chrono::milliseconds(deadline), [&] { return st->done; });
-        if (!finished) st->abandoned.store(true);   // under st->m: the thread checks it under the same mutex before publishing
+        if (!finished) {
+          st->abandoned.store(true);   // under st->m: the thread checks it under the same mutex before publishing
+          // ... and everybody else who waits on this set-up leaves now (the helper thread may be hung inside ncclCommInitAll for good)
+          st->rc = TOR_ERR_HIP;
+          st->err = "RCCL: communicator creation + self-check did not return within the first caller's deadline (TOR_RCCL_INIT_TIMEOUT_MS); abandoned";
+          st->done = true;
+          st->cv.notify_all();
+        }
       }
       std::lock_guard<std::mutex> lock(g_comm_mutex);
       g_comm_pending.erase(j.key);
       if (!finished) {
-        g_comm_timed_out.insert(j.key);
+        g_comm_timed_out[j.key] = std::chrono::steady_clock::now();
         return fail(TOR_ERR_HIP, "RCCL: communicator creation + self-check did not return within " + std::to_string(deadline) +
                                      " ms (TOR_RCCL_INIT_TIMEOUT_MS); abandoned (the helper thread destroys whatever it still creates)");
       }

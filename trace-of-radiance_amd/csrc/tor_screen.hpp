@@ -153,7 +153,10 @@ TOR_HD ScreenSeg screen2_seg(const ScreenRay& r, double reach, double travel, do
   const double B = r.s1 + reach + travel * __builtin_fabs(f);
   const double mu = TOR_MARGIN(B * 0x1p-47);
   const double M = TOR_MARGIN((B * B) * 0x1p-45);
-  const bool wild = r.wild || !((B * B) * 0x1p-45 < __builtin_inf());
+  // (f * f must stay finite too: f2n = sg2 f^2 below meets dcy = 0 -- a static that rests in a segment of movers along y -- as
+  // inf x 0 = NaN otherwise, and the NaN's clear sign bit would DROP a sphere the reference hits.  |f| > 1.3e154 with
+  // travel |f| still below the B^2 limit needs travel < 1: random_scene's movers, shutter_close ~ 1e155.  ADVICE r5.)
+  const bool wild = r.wild || !((B * B) * 0x1p-45 < __builtin_inf()) || !(f * f < __builtin_inf());
   // sigma = 2^-(e + 2) for B in [2^e, 2^(e+1)): sigma B < 1/2.  (B = 0 or denormal: 2^1020; harmless, every product below is 0 or tiny)
   uint64_t e = (double_to_bits(B) >> 52) & 0x7ffu;
   if (e < 3u) e = 3u;
