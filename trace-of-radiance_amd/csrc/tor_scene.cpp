@@ -670,7 +670,12 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
           const size_t pos = k + 1;
           if (pos % unit != 0) continue;
           const double cost = half_area(lo, hi) * (double)pos + suffix[pos] * (double)(n_here - pos);
-          if (cost < best_cost) { best_cost = cost; best_pos = pos; best_ord = cand; have = true; }
+          // (ties -- many identical spheres: every split costs the same -- go to the most balanced split: the build stays
+          // n log^2 n instead of peeling one block per node)
+          auto off_middle = [&](size_t q_) { return q_ > n_here / 2 ? q_ - n_here / 2 : n_here / 2 - q_; };
+          if (cost < best_cost || (have && cost == best_cost && off_middle(pos) < off_middle(best_pos))) {
+            best_cost = cost; best_pos = pos; best_ord = cand; have = true;
+          }
         }
         if (!have && ax == 0) best_ord = cand;
       }
