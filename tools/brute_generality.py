@@ -6,7 +6,7 @@ Workloads -- the bench scene and scenes that share none of its coincidences -- x
 for every object), TOR_SCREEN=0 (the reference's unfused loop)}, per-sample streams, accel 0.  Every canvas is compared with the
 unscreened one and the resolve pass's candidate count with TOR_PLANE=0's (stage one must never change what stage two leaves).
 
-    python tools/brute_generality.py [--out gpurun_out/r5_brute_generality.txt] [--spp 100]
+    python tools/brute_generality.py [--out gpurun_out/r6_brute_generality.txt] [--spp 100]
 """
 import argparse
 import importlib
@@ -69,7 +69,7 @@ def workloads(H, W):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default="gpurun_out/r5_brute_generality.txt")
+    ap.add_argument("--out", default="gpurun_out/r6_brute_generality.txt")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--spp", type=int, default=100)

@@ -2,7 +2,10 @@
 annotations LLVM leaves in the ISA: make -C trace-of-radiance_amd/csrc asm), by instruction class -- and, with --weights FILE, a
 dynamic estimate per bounce iteration: every loop's count times its measured trips (rocprofv3 PC sampling is not available on this
 pool's boxes, so this is the only per-class view there is; the total is checked against SQ_INSTS_VALU of the same launch).
-usage: python tools/isa_dynamic.py [name part] [--weights tools/isa_weights_<variant>.json] [--blocks]"""
+usage: python tools/isa_dynamic.py [name part] [--weights tools/isa_weights_<variant>.json] [--blocks] [--lines <.s built with -gline-tables-only>]
+--lines: where the SPILL instructions sit -- v_readlane / v_writelane (scalar registers spilled to VGPR lanes) and scratch loads / stores
+(VGPRs spilled to memory) by loop depth and source file, from the .loc tables of a line-table build of the same source
+(hipcc <CXXFLAGS of csrc/Makefile> -gline-tables-only -S --cuda-device-only -o /tmp/tor_kernels_g.s tor_kernels.hip)."""
 import collections, json, os, re, sys
 path = os.environ.get("TOR_ASM") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trace-of-radiance_amd", "lib", "asm", "tor_kernels.s")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -115,3 +118,47 @@ if wfile:
     for c in CLASSES:
         print(f"  {c:45s} {tot[c]:8.1f}" + (f"   {tot[c] / v:6.3f} of the vector instructions" if c in VALU else ""))
     print(f"  vector instructions in all {v:8.1f}   (measured: {weights.get('measured_valu_per_iteration', '?')})")
+
+if "--lines" in sys.argv:
+    gpath = sys.argv[sys.argv.index("--lines") + 1]
+    gtext = open(gpath).read().split("\n")
+    files = {}
+    for l in gtext:
+        m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"\s+"([^"]*)"', l)
+        if m:
+            files[int(m.group(1))] = m.group(3).split("/")[-1]
+    g0 = next(i for i, l in enumerate(gtext) if re.match(r"^_ZN3tor16integrate_kernel\w*:", l) and want in l)
+    g1 = next(j for j in range(g0, len(gtext)) if "s_endpgm" in gtext[j])
+    cur, depth = ("?", 0), 0
+    lane, scr = collections.Counter(), collections.Counter()
+    for l in gtext[g0:g1]:
+        m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", l)
+        if m:
+            cur = (files.get(int(m.group(1)), "?"), int(m.group(2)))
+            continue
+        if l.startswith(".LBB") or l.startswith("; %bb"):
+            mm = re.search(r"in Loop: Header=\S+ Depth=(\d+)", l)
+            depth = int(mm.group(1)) if mm else (0 if "Depth" not in l else depth)
+            mm = re.search(r"Loop Header: Depth=(\d+)", l)
+            if mm:
+                depth = int(mm.group(1))
+            continue
+        if "Loop Header: Depth=" in l:
+            depth = int(re.search(r"Depth=(\d+)", l).group(1))
+            continue
+        t = l.strip().split()
+        if not t:
+            continue
+        if t[0].startswith(("v_readlane", "v_writelane")):
+            lane[(depth, cur[0], t[0][:10])] += 1
+        if t[0].startswith("scratch_"):
+            scr[(depth, cur[0], t[0])] += 1
+    print("\nspill instructions by loop depth (0 = outside every loop, 1 = the bounce loop's own body, 2 = the pass / segment loop, 3+ = the inner loops) and source file")
+    for k, v in sorted(lane.items()):
+        print(f"  depth {k[0]}  {k[1]:34s} {k[2]:12s} {v:4d}")
+    for k, v in sorted(scr.items()):
+        print(f"  depth {k[0]}  {k[1]:34s} {k[2]:22s} {v:4d}")
+    by_depth = collections.Counter()
+    for k, v in lane.items():
+        by_depth[k[0]] += v
+    print("  lane reads / writes per depth:", dict(sorted(by_depth.items())))

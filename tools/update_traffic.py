@@ -12,15 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # strict brute force runs behind the FMA screen = ARITH 2; the exact accelerations keep ARITH 0).  A summary whose dominant
 # integrate_kernel is another variant is an ERROR (bench.py must not replay counters of a kernel it does not run).
 CONFIGS = {
-    "1920x1080x100:sample:strict": ("r5_c2_summary.txt", (1, 2, 3, 0, 0)),
-    "1920x1080x100:pixel:strict": ("r5_c2_pixel_brute_summary.txt", (0, 2, 3, 0, 0)),
-    "1920x1080x1000:sample:strict": ("r5_c3_summary.txt", (1, 2, 3, 0, 0)),
-    "1920x1080x100:sample:strict:f32": ("r5_c2_f32_summary.txt", (1, 0, 3, 1, 0)),
-    "1920x1080x100:sample:strict:blocks": ("r5_c2_blocks_summary.txt", (1, 0, 3, 0, 1)),
-    "1920x1080x100:sample:strict:blocks+f32": ("r5_c2_accel3_summary.txt", (1, 0, 3, 1, 1)),
-    "1920x1080x1000:sample:strict:blocks+f32": ("r5_c3_accel3_summary.txt", (1, 0, 3, 1, 1)),
-    "1920x1080x100:pixel:strict:blocks+f32": ("r5_c2_pixel_default_summary.txt", (0, 0, 3, 1, 1)),
-    "1920x1080x1000:pixel:strict:blocks+f32": ("r5_c3_pixel_default_summary.txt", (0, 0, 3, 1, 1)),
+    "1920x1080x100:sample:strict": ("r6_c2_summary.txt", (1, 2, 3, 0, 0)),
+    "1920x1080x100:pixel:strict": ("r6_c2_pixel_brute_summary.txt", (0, 2, 3, 0, 0)),
+    "1920x1080x1000:sample:strict": ("r6_c3_summary.txt", (1, 2, 3, 0, 0)),
+    "1920x1080x100:sample:strict:f32": ("r6_c2_f32_summary.txt", (1, 0, 3, 1, 0)),
+    "1920x1080x100:sample:strict:blocks": ("r6_c2_blocks_summary.txt", (1, 0, 3, 0, 1)),
+    "1920x1080x100:sample:strict:blocks+f32": ("r6_c2_accel3_summary.txt", (1, 0, 3, 1, 1)),
+    "1920x1080x1000:sample:strict:blocks+f32": ("r6_c3_accel3_summary.txt", (1, 0, 3, 1, 1)),
+    "1920x1080x100:pixel:strict:blocks+f32": ("r6_c2_pixel_default_summary.txt", (0, 0, 3, 1, 1)),
+    "1920x1080x1000:pixel:strict:blocks+f32": ("r6_c3_pixel_default_summary.txt", (0, 0, 3, 1, 1)),
 }
 
 
@@ -43,7 +43,7 @@ def counters(path, variant):
         raise SystemExit(f"{path}: no integrate_kernel dispatch in the summary")
     dominant = max(seen, key=seen.get)
     if dominant != want:
-        raise SystemExit(f"{path}: the dominant kernel is {dominant}, but this mode launches {want} -- re-profile (tools/profile_round5.sh)")
+        raise SystemExit(f"{path}: the dominant kernel is {dominant}, but this mode launches {want} -- re-profile (tools/profile_round6.sh)")
     out["_ms"] = seen[want]
     return {k: v for k, v in out.items() if not k.startswith("_ms_")}
 
@@ -56,7 +56,7 @@ def main():
     for key, (fname, variant) in CONFIGS.items():
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
-            raise SystemExit(f"profiles/{fname} is missing (tools/profile_round5.sh makes it)")
+            raise SystemExit(f"profiles/{fname} is missing (tools/profile_round6.sh makes it)")
         c = counters(path, variant)
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
