@@ -849,7 +849,7 @@ bool compute_block_bounds(const HostAccel& acc, double t_lo, double t_hi, std::v
       bnd[8 * b + 3 + a] = hi[a] + pad;
     }
   }
-  // second level: one box around every 8 consecutive block boxes (the blocks follow the Morton
+  // second level: one box around every 8 consecutive block boxes (the build aligns its upper splits to 64 objects
   // curve, so the groups are compact); stored behind the block boxes, padded with NaN boxes
   const size_t n_super = n_bnd_p / kPad;
   const size_t n_super_p = (n_super + kPad - 1) / kPad * kPad;

@@ -50,7 +50,7 @@ bool build_layout(const TorHittableVariant* objs, const std::vector<int64_t>& id
                   const F32Options* f32 = nullptr);
 
 // Acceleration layout (TOR_ACCEL_BLOCKS): large or irregular objects stay in an "always" brute-force
-// layout; the rest are sorted along a Morton curve and cut into blocks of 8 consecutive objects.
+// layout; the rest are ordered by a top-down surface-area build (tor_scene.cpp build_accel) and cut into blocks of 8 consecutive objects.
 // Per render call the blocks get conservative bounding spheres (they depend on the ray-time range).
 struct HostAccel {
   bool available = false;
