@@ -274,7 +274,15 @@ __global__ __launch_bounds__(kThreads, WAVES_PER_SIMD) void integrate_kernel(con
   if (staged) {
     if (F32) {
       for (int k = threadIdx.x; k < p.shot32_lds_floats; k += kThreads) stage32[k] = p.shot32[k];
-      for (int k = threadIdx.x; k < p.bnd32_lds_floats; k += kThreads) stage_b32[k] = p.bnd32[k];
+      // block boxes of two-level scenes, TRANSPOSED on the way in: child j of super box s at ((j * n_super + s) * 6 .. + 6) -- 24 bytes,
+      // read as three ds_read_b64.  In the table's own order (s * 64 + j * 8 floats) the 64 lanes of a pooled expansion -- 64
+      // different super boxes, the same child j -- all start in ONE bank: 58 % of the LDS cycles of the 1601-sphere animation
+      // frames were bank conflicts (round 6: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, 28 % on random_scene, 17 % unstaged)
+      const int n_sup_lds = p.bnd32_lds_floats / (8 * kBlock);
+      for (int k = threadIdx.x; k < p.bnd32_lds_floats; k += kThreads) {
+        const int c = k & 7, b = k >> 3;
+        if (c < 6) stage_b32[((b & 7) * n_sup_lds + (b >> 3)) * 6 + c] = p.bnd32[k];
+      }
     } else {
       for (int k = threadIdx.x; k < p.shot_lds_doubles; k += kThreads) stage[k] = p.shot[k];
     }

@@ -16,7 +16,11 @@ constexpr int kPad = 8;        // hot-record arrays are padded to a multiple of 
 // TOR_ACCEL_BLOCKS: blocks of 8 objects behind ONE culling box (box b = blocks [b F, (b + 1) F)).  A compile-time constant: the
 // round-4 experiment ran it as a launch parameter (commit c39354b, profiles/r4_fanout_sweep.txt: 56.4 / 59.0 / 73.0 / 115.3 ms for
 // F = 1 / 2 / 4 / 8 on configs[1] with both accelerations) and the run-time loops alone cost the accelerated kernels 2-3 %.
+#ifdef TOR_BOX_FANOUT
+constexpr int kBoxFanout = TOR_BOX_FANOUT;  // (A/B builds only)
+#else
 constexpr int kBoxFanout = 1;
+#endif
 
 // Device scene (built by tor_scene_upload from the AoS HittableVariant list):
 //   stat : static spheres, 4 float64 each   {cx, cy, cz, radius^2}

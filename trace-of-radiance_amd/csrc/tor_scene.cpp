@@ -620,7 +620,7 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
     std::stable_sort(keyed.begin(), keyed.end());
   } else {
     const size_t ns = spatial.size();
-    const bool second_level = (ns + kPad - 1) / kPad > kTwoLevelMinBlocks;
+    const bool second_level = ((ns + kPad - 1) / kPad + (size_t)kBoxFanout - 1) / (size_t)kBoxFanout > kTwoLevelMinBlocks;
     struct Hull { double lo[3], hi[3], mid[3]; };
     std::vector<Hull> hull(ns);
     for (size_t k = 0; k < ns; ++k) {
@@ -650,7 +650,9 @@ void build_accel(const TorHittableVariant* objs, int64_t n, HostAccel& out, cons
       todo.pop_back();
       const size_t n_here = e - b;
       if (n_here <= (size_t)kPad) continue;
-      const size_t unit = (second_level && n_here > (size_t)(kPad * kPad)) ? (size_t)(kPad * kPad) : (size_t)kPad;
+      // (a culling box stands for kBoxFanout blocks -- 1 in every shipped build --, a super box for 8 boxes)
+      const size_t box_objs = (size_t)kPad * (size_t)kBoxFanout;
+      const size_t unit = (second_level && n_here > box_objs * kPad) ? box_objs * kPad : (n_here > box_objs ? box_objs : (size_t)kPad);
       double best_cost = INFINITY;
       size_t best_pos = (n_here / 2 + unit - 1) / unit * unit;  // fall-back (non-finite areas): the median, on x
       if (best_pos >= n_here) best_pos = (n_here - 1) / unit * unit;
