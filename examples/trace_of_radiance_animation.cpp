@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
   opt.device = -1;
   opt.shard_count = 1;
   opt.row_tile = 1;
-  opt.accel = TOR_ACCEL_BLOCKS;        // ~1600 spheres per frame: exact block culling, identical pixels
+  opt.accel = TOR_ACCEL_BLOCKS | TOR_ACCEL_F32;  // ~1600 spheres per frame: both exact accelerations (what tor_render() defaults to), identical pixels
 
   std::vector<TorHittableVariant> objects((size_t)tor_animation_object_count(anim));
   std::vector<uint8_t> slice((size_t)fn);

@@ -27,6 +27,7 @@ prof r6_c2_accel3 --spp 100 --accel blocks+f32
 prof r6_c3_accel3 --spp 1000 --accel blocks+f32
 prof r6_c2_pixel_default --spp 100 --seeding pixel --accel blocks+f32
 prof r6_c3_pixel_default --spp 1000 --seeding pixel --accel blocks+f32
+prof r6_c5 --workload c5 --frames 3
 python tools/brute_generality.py --out $O/r6_brute_generality.txt > $O/r6_brute_generality.log 2>&1
 SPP=50 python tools/section_probe.py > $O/r6_section_probe_c2x50.txt 2>&1
 if [ -f trace-of-radiance_amd/lib/libtor_mi355x_fine.so ]; then   # (make -C trace-of-radiance_amd/csrc fine)
