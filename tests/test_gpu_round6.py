@@ -100,3 +100,44 @@ def test_cost_probe_counts_the_same_queries_on_every_layout(tor):
         assert np.array_equal(c, base), key
     st, _ = _stats(tor, scene, cam, h, w, 2, 0, tor.SEED_SAMPLE)
     assert int(base.sum()) == st.hit_queries
+
+
+def _dense_cluster(n_small, n_big, jitter=0.01, movers=False, seed=7):
+    """Spheres that nearly coincide: every ray towards the cluster keeps EVERY object of every block it enters (8 survivors per
+    (ray, block) pair) and every big sphere (direct survivors) -- the worst case for the pooled lists of the cooperative resolve."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for k in range(n_big):   # > 2.5 x the median radius: outside the blocks, tested directly; BEHIND the cluster as the camera sees it
+        c = rng.uniform(-jitter, jitter, 3) + (0.0, 0.0, -3.0)
+        recs.append([0, *c, *c, 0, 1, 1.0 + 0.01 * k, 2 if k % 2 else 0, .6, .7, .8, 0, 1.5])
+    for k in range(n_small):
+        c = rng.uniform(-jitter, jitter, 3)
+        mat = int(rng.integers(0, 3))
+        if movers and k % 3 == 0:
+            recs.append([1, *c, *(c + (0, 0.05, 0)), 0, 1, 0.2 + 0.0005 * k, mat, .8, .5, .3, 0.1, 1.5])
+        else:
+            recs.append([0, *c, *c, 0, 1, 0.2 + 0.0005 * k, mat, .8, .5, .3, 0.1, 1.5])
+    return np.asarray(recs, dtype=np.float64)
+
+
+def test_pooled_lists_hold_the_worst_case(tor, oracle):
+    """Cooperative resolve (integrate_resolve_coop.inc): the survivor list takes up to 8 entries per lane from ONE block-expansion trip
+    on top of what the list-building step left there.  Scenes of nearly coincident spheres fill both at once: 8 direct survivors and
+    8 entered blocks per ray, 8 kept objects per (ray, block) pair.  Every accel mode must still equal the brute force, and the brute
+    force the oracle."""
+    import torch
+    cam = tor.camera(look_from=(0.3, 0.2, 5.0), look_at=(0, 0, 0), vertical_field_of_view=12.0, aperture=0.0, focus_distance=5.0)
+    ocam = np.frombuffer(bytes(cam), dtype=np.float64).copy()
+    h, w, spp, depth = 24, 32, 8, 6
+    for name, recs in (("8 big + 64 small", _dense_cluster(64, 8)),
+                       ("4 big + 72 small, movers", _dense_cluster(72, 4, movers=True)),
+                       ("8 big + 200 small", _dense_cluster(200, 8)),
+                       ("40 big + 900 small (two levels)", _dense_cluster(900, 40, jitter=0.05))):
+        scene = tor.Scene.from_records(recs)
+        for seeding in (tor.SEED_SAMPLE, tor.SEED_PIXEL):
+            brute, _ = _render_with_env(tor, scene, cam, h, w, spp, {}, depth=depth, seeding=seeding, accel=0, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+            want = oracle.render(h, w, spp, ocam, recs, max_depth=depth, seeding=seeding, math=oracle.MATH_PORTABLE, accum=seeding).pixels
+            _exact(brute.cpu().numpy(), want)
+            for accel in (1, 2, 3):
+                got, _ = _render_with_env(tor, scene, cam, h, w, spp, {}, depth=depth, seeding=seeding, accel=accel, pixel_kernel=tor.PIXEL_KERNEL_LANE)
+                assert torch.equal(got, brute), (name, seeding, accel, int((got != brute).sum().item()))

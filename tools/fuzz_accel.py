@@ -4,8 +4,9 @@ discriminant for every object) and the brute force with stage one of the screen 
 table (TOR_PLANE=2: no gate) -- against the float64 brute-force canvas (default: the host's gate and the waves' votes decide per
 segment), bit for bit.
 Usage: python tools/fuzz_accel.py [seconds] [seed] [heights] [--oracle K]
-    heights: mixed (default: half of the scenes rest their spheres on 1-4 common heights) | none (every sphere at its own height: no
-             common-height segment anywhere -- the round-5 record)
+    heights: mixed (default: half of the scenes rest their spheres on 1-4 common heights; 15 % are dense, see below) | none (every sphere
+             at its own height: no common-height segment anywhere -- the round-5 record) | dense (every scene: 1-3 clusters of nearly
+             coincident spheres, the worst case of the pooled lists and of every candidate queue)
     --oracle K (round 6): every K-th scene is ALSO rendered by the CPU oracle (oracle/tor_oracle.c: the restatement of the reference,
              PORTABLE math, the accumulation of the stream mode) in both stream modes and the GPU brute force must equal it bit for bit --
              a GPU-vs-GPU diff cannot see a defect in what every loop family shares (layout, padding, segment order); the oracle
@@ -41,8 +42,15 @@ def random_scene(rng):
     # spheres resting at a few common heights (bit-identical c0.y: the strict loop's common-height segments and the plane screen in
     # front of them) in half of the scenes; any height in the others
     levels = shift[1] + rng.uniform(0, 0.3 * spread, int(rng.integers(1, 5))) if (HEIGHTS == "mixed" and rng.random() < 0.5) else None
+    # dense scenes (round 6, after the pooled survivor list of the cooperative resolve was found to overflow on them): 1-3 clusters of
+    # nearly coincident spheres -- a ray through a cluster keeps EVERY object of every block it enters, and every larger sphere
+    dense = HEIGHTS == "dense" or (HEIGHTS == "mixed" and rng.random() < 0.15)
+    centres = shift + rng.uniform(-0.3, 0.3, (int(rng.integers(1, 4)), 3)) * spread * (1, 0.3, 1) + (0, 0.1 * spread, 0)
+    tight = float(rng.choice([0.002, 0.02, 0.1])) * rscale
     while len(recs) < n:
         c = shift + np.array([rng.uniform(-spread, spread), rng.uniform(0, 0.3 * spread), rng.uniform(-spread, spread)])
+        if dense and rng.random() < 0.9:
+            c = centres[int(rng.integers(0, len(centres)))] + rng.uniform(-tight, tight, 3)
         if levels is not None and rng.random() < 0.9:
             c[1] = levels[int(rng.integers(0, len(levels)))]
         r = float(rng.choice([0.15, 0.2, 0.3, 0.45, 1.0])) * rscale * (1 if rng.random() > 0.03 else -1)
