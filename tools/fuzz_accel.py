@@ -103,7 +103,7 @@ def main():
         recs, cam = random_scene(rng)
         scene = tor.Scene.from_records(recs)
         h, w = int(rng.choice([16, 24, 40])), int(rng.choice([26, 34, 64]))
-        spp, depth = int(rng.choice([2, 6, 33])), int(rng.choice([3, 12, 50]))
+        spp, depth = int(rng.choice([2, 6, 33, 40])), int(rng.choice([3, 12, 50]))
         for seeding in (0, 1):
             canv = []
             for accel in (0, 1, 2, 3):
@@ -147,6 +147,17 @@ def main():
                 if not np.array_equal(canv[0], cv.pixels, equal_nan=True):
                     bad += 1
                     print(f"MISMATCH scene {n_scenes} (n={len(recs)}) wave-per-pixel kernel: {int((canv[0] != cv.pixels).sum())} values differ", flush=True)
+            if seeding == 0:
+                # what tor_render() runs when nothing is set (round 6): the library picks the pixel kernel itself (TorOptions.pixel_kernel = 0)
+                # -- the chain hand-off with its server waves (>= 32 spp, single-level culling layout), split mode, or one wave per pixel
+                for accel in (3, 0):
+                    cv = tor.new_canvas(h, w, spp, 2.2)
+                    tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=0, accel=accel))
+                    n_renders += 1
+                    if not np.array_equal(canv[0], cv.pixels, equal_nan=True):
+                        bad += 1
+                        print(f"MISMATCH scene {n_scenes} (n={len(recs)}) library's own choice of pixel kernel, accel {accel}: "
+                              f"{int((canv[0] != cv.pixels).sum())} values differ; note: {tor.last_note()!r}", flush=True)
             for accel in (1, 2, 3):
                 if not np.array_equal(canv[0], canv[accel], equal_nan=True):
                     bad += 1
