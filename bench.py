@@ -532,7 +532,7 @@ def bench_animation(args, tor, torch, dist, world, rank, local_rank):
                 ocam, oobjs = c_, o_
             result["cpu_baseline"] = cpu_baseline(W, H, spp, args.depth, args.cpu_seconds, objs=oobjs, cam=ocam,
                                                   scene_name=f"animation frame {mid_f} ({len(oobjs)} objects; the oracle's restatement of scenes_animated.nim, parity-unpinned)")
-        print(json.dumps(result), flush=True)
+        emit_line(json.dumps(result))
 
 
 def algorithmic_flops_per_sample(scene, tor, queries_per_sample=2.6022):
@@ -628,7 +628,7 @@ def bench_single_process_multi_device(args, tor):
     if per_dev and per_dev[0] > 0:
         roof["hbm"]["achieved"] = round(roof["hbm"]["algorithmic_bytes_per_launch"] / (per_dev[0] * 1e-3) / 1e9, 4)
         roof["hbm"]["frac"] = round(roof["hbm"]["achieved"] / PEAK_HBM_GBPS, 8)
-    print(json.dumps({
+    emit_line(json.dumps({
         "metric": "Msamples/s (pixels×spp/s) on book-1 random_scene", "value": round(value, 2),
         "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -644,13 +644,35 @@ def bench_single_process_multi_device(args, tor):
                                 "speedup": round(value / n1_value, 3), "region": "the same frame and region on devices[0] alone"},
         "last_call_ms": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
         "canvas_identical_to_single_device": verified, "roofline": roof,
-        "cpu_baseline": cpu if cpu is not None else {"value": None, "note": "skipped (--no-cpu-baseline)"}}), flush=True)
+        "cpu_baseline": cpu if cpu is not None else {"value": None, "note": "skipped (--no-cpu-baseline)"}}))
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """stdout carries ONE line, the JSON line of rank 0: whatever else writes to file descriptor 1 from here on -- the banners RCCL
+    and gloo print when a communicator comes up, children -- lands on stderr instead."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
 def main():
     args = parse_args()
     if args.pmc_child:
         return pmc_child(args.pmc_child)
+    claim_stdout()
     import torch
     import torch.distributed as dist
 
@@ -1097,7 +1119,7 @@ def main():
         # (N > 1: after the process group is gone -- the other ranks have left, the host cores are free again)
         result["cpu_baseline"] = (cpu_baseline(W, H, args.spp, args.depth, args.cpu_seconds) if not args.no_cpu_baseline
                                   else {"value": None, "note": "skipped (--no-cpu-baseline)"})
-        print(json.dumps(result), flush=True)
+        emit_line(json.dumps(result))
 
 
 if __name__ == "__main__":
