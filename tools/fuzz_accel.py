@@ -3,7 +3,7 @@ WITHOUT its conservative FMA screen (TOR_SCREEN=0, DESIGN 4.2: no plane screen, 
 discriminant for every object) and the brute force with stage one of the screen FORCED onto every segment that carries a plane
 table (TOR_PLANE=2: no gate) -- against the float64 brute-force canvas (default: the host's gate and the waves' votes decide per
 segment), bit for bit.
-Usage: python tools/fuzz_accel.py [seconds] [seed] [heights] [--oracle K]
+Usage: python tools/fuzz_accel.py [seconds] [seed] [heights] [--oracle K] [--big K]
     heights: mixed (default: half of the scenes rest their spheres on 1-4 common heights; 15 % are dense, see below) | none (every sphere
              at its own height: no common-height segment anywhere -- the round-5 record) | dense (every scene: 1-3 clusters of nearly
              coincident spheres, the worst case of the pooled lists and of every candidate queue)
@@ -77,6 +77,12 @@ def random_scene(rng):
 
 def main():
     argv = list(sys.argv[1:])
+    big_every = 0
+    if "--big" in argv:   # every K-th scene once more at 108 x 192 x 40 spp: hundreds of tiles, every wave of the machine, dedicated servers
+        k = argv.index("--big")
+        big_every = int(argv[k + 1])
+        del argv[k:k + 2]
+    n_big = 0
     oracle_every = 0
     if "--oracle" in argv:
         k = argv.index("--oracle")
@@ -163,7 +169,25 @@ def main():
                     bad += 1
                     print(f"MISMATCH scene {n_scenes} (n={len(recs)}) seeding {seeding} accel {accel}: "
                           f"{int((canv[0] != canv[accel]).sum())} values differ", flush=True)
+        if big_every > 0 and n_scenes % big_every == 0:
+            # a frame large enough for the SEED_PIXEL schedule to matter: the cost probe, the tile order, dedicated server waves,
+            # hand-offs from waves all over the machine -- the library's own choice of kernel against the lane kernel's brute force
+            bh, bw, bspp = 108, 192, 40
+            ref = tor.new_canvas(bh, bw, bspp, 2.2)
+            tor.render(ref, cam, scene.list(), depth, tor.make_options(seeding=0, accel=0, pixel_kernel=1))
+            n_renders += 1
+            n_big += 1
+            for accel, pk in ((3, 0), (0, 0), (3, 1)):
+                cv = tor.new_canvas(bh, bw, bspp, 2.2)
+                tor.render(cv, cam, scene.list(), depth, tor.make_options(seeding=0, accel=accel, pixel_kernel=pk))
+                n_renders += 1
+                if not np.array_equal(ref.pixels, cv.pixels, equal_nan=True):
+                    bad += 1
+                    print(f"MISMATCH scene {n_scenes} (n={len(recs)}) {bh}x{bw}x{bspp} accel {accel} pixel_kernel {pk}: "
+                          f"{int((ref.pixels != cv.pixels).sum())} values differ; note: {tor.last_note()!r}", flush=True)
         n_scenes += 1
+    if big_every > 0:
+        print(f"  ({n_big} scenes also at 108x192x40 through the library's own choice of pixel kernel)", flush=True)
     print(f"fuzz (heights: {HEIGHTS}): {n_scenes} scenes, {n_renders} renders, {n_oracle} of them checked against the CPU oracle "
           f"(every {oracle_every or '-'}th scene, both stream modes), {bad} mismatches in {time.time() - t0:.0f} s", flush=True)
     sys.exit(1 if bad else 0)
