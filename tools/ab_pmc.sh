@@ -3,7 +3,7 @@
 # (one configs[1]-sized launch pair through the bare C ABI), for the in-tree library and for TOR_AB_LIB.
 # usage (inside gpurun): bash tools/ab_pmc.sh [other.so]   -> gpurun_out/ab_pmc.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OTHER=${1:-$R/trace-of-radiance_amd/lib/libtor_mi355x_r4.so}
+OTHER=${1:-$R/trace-of-radiance_amd/lib/libtor_mi355x_old.so}
 OUT=$R/gpurun_out/ab_pmc.txt
 mkdir -p $R/gpurun_out; : > $OUT
 export TMPDIR=/tmp TOR_NO_TORCH=1
